@@ -1,0 +1,147 @@
+/*
+ * ste.h — C ABI of the MI355X-native batched UKF + URTSS path ("ship-track-estimators", ste).
+ *
+ * The reference (NOC-OI/ship-track-estimators) is pure Python and has no FFI of its own; its boundary for this path
+ * is the Python API.  Each entry point below is the batched, device-resident counterpart of one
+ * reference method and is what a reference-side binding (ctypes) would load:
+ *
+ *   ste_ukf_forward_f64      KalmanFilterBase.run            src/track_estimators/kalman_filters/kalman_filter.py:36-117
+ *                            (+ UnscentedKalmanFilter.predict / .update, kalman_filters/unscented.py:144-265)
+ *   ste_urtss_backward_f64   KalmanFilterBase.run_rts_smoother kalman_filter.py:119-137
+ *                            (+ UnscentedKalmanFilter.rts_step, unscented.py:267-351)
+ *   ste_ukf_urtss_f64        both, back to back on one stream (examples/example_ukf_rts_smoother_batch.py:75-87)
+ *   ste_geodetic_dynamics_f64  geodetic_dynamics              kalman_filters/non_linear_process.py:6-85
+ *   ste_sigma_points_f64     UnscentedKalmanFilter.compute_sigma_points  unscented.py:76-107
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every array pointer is a DEVICE pointer unless marked HOST; the caller owns every buffer, the library never
+ *     allocates outputs or frees inputs.
+ *   - calls are asynchronous on `stream`; no global state except a thread-local error string.
+ *   - return 0 on success, a negative STE_E* code on argument / launch errors (message via ste_last_error()).
+ *   - per-track numerical trouble never aborts a batch: it is reported in status[] (mirrors the batch example's
+ *     try/except/continue, example_ukf_rts_smoother_batch.py:73-90).
+ *   - state order [lon deg, lat deg, speed km/h, heading deg], time in hours (non_linear_process.py:54-57).
+ *
+ * Data layout in HBM: structure-of-arrays with the TRACK index fastest, so that consecutive lanes (= consecutive
+ * tracks) read and write consecutive 8-byte words:
+ *      per-step scalar   a[k][t]            -> a[k*B + t]
+ *      per-step vector   v[k][c][t]         -> v[(k*4 + c)*B + t]
+ *      per-step matrix   M[k][r][c][t]      -> M[(k*16 + r*4 + c)*B + t]
+ */
+#ifndef STE_H
+#define STE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STE_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define STE_OK 0
+#define STE_EINVAL (-1)   /* bad argument (NULL pointer, B <= 0, n != 4 ...) */
+#define STE_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define STE_ENOGPU (-3)   /* no HIP device visible */
+
+/* ste_ukf_batch_f64.flags */
+#define STE_FLAG_SHARED_P0 0x1u        /* P0 is one 4x4 matrix [16] shared by all tracks (else [16][B]) */
+#define STE_FLAG_NO_INITIAL_UPDATE 0x2u /* skip the update with z[:,0] that run() performs before the first predict */
+
+/* status[] bits (per track) */
+#define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
+#define STE_STATUS_CLAMPED 0x2    /* sigma fan: negative eigenvalue clamped to 0 (sqrtm went complex in the reference) */
+#define STE_STATUS_NOCONV 0x4     /* Jacobi eigen-solve hit its sweep cap */
+
+/*
+ * One batch of B independent tracks, padded to Nmax filter steps and Tmax observations.
+ * n must be 4 (the reference hard-codes index 3 as the heading, unscented.py:250).
+ */
+typedef struct ste_ukf_batch_f64 {
+    int32_t B;     /* number of tracks */
+    int32_t Nmax;  /* padded number of filter steps (len(dt) in run()) */
+    int32_t Tmax;  /* padded number of observations (columns of ShipTrack.z) */
+    int32_t n;     /* state dimension, must be 4 */
+    uint32_t flags;
+    int32_t reserved;
+
+    /* sigma-fan constants, computed by the host exactly as unscented.py:95,125,132 does (HOST values) */
+    double fan_scale; /* n / (1 - W0) */
+    double w0;        /* 1 - n/3 */
+    double wi;        /* (1 - W0) / (2n) */
+
+    /* shared 4x4 matrices, row-major, HOST pointers read at call time (unscented.py:55-61) */
+    const double* H;
+    const double* Q;
+    const double* R;
+
+    /* per-track inputs (device) */
+    const int32_t* nsteps; /* [B] real step count of each track (<= Nmax); NULL = every track has Nmax steps */
+    const double* x0;      /* [4][B]  prior mean */
+    const double* P0;      /* [16][B] prior covariance, or [16] with STE_FLAG_SHARED_P0 */
+
+    /* per-step inputs (device) */
+    const double* dt;           /* [Nmax][B]  kalman_filter.py:88 */
+    const double* sog_rate;     /* [Nmax][B]  rate used by predict at step k  (kalman_filter.py:93) */
+    const double* cog_rate;     /* [Nmax][B]                                   (kalman_filter.py:94) */
+    const double* sog_rate_rts; /* [Nmax][B]  rate used by the smoother at step k (unscented.py:287-292,310); NULL = sog_rate */
+    const double* cog_rate_rts; /* [Nmax][B]  NULL = cog_rate */
+    const int32_t* upd_idx;     /* [Nmax][B]  observation column consumed after step k, -1 = no update (kalman_filter.py:101-108) */
+    const double* z;            /* [Tmax][4][B] measurement matrix columns (ship_track.py:324-336) */
+
+    /* recorded noise draws, already scaled; NULL = zero noise (unscented.py:198,232,320) */
+    const double* noise_pred; /* [Nmax][4][B]   added to the predicted mean of step k */
+    const double* noise_upd;  /* [Nmax+1][4][B] row 0: initial update; row k+1: update after step k */
+    const double* noise_rts;  /* [Nmax][4][B]   added to the back-predicted mean of step k */
+
+    /* outputs (device) */
+    double* fwd_mean; /* [Nmax+1][4][B]  row 0 = prior (kalman_filter.py:76) */
+    double* fwd_cov;  /* [Nmax+1][16][B] */
+    double* sm_mean;  /* [Nmax+1][4][B]  smoothed; row nsteps = filtered row nsteps */
+    double* sm_cov;   /* [Nmax+1][16][B] */
+    int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
+} ste_ukf_batch_f64;
+
+int ste_version(void);
+
+/* Thread-local message of the last failing call on this thread; valid until the next call on this thread. */
+const char* ste_last_error(void);
+
+/* Number of HIP devices visible (0 if none / runtime unavailable). Does not select a device. */
+int ste_device_count(void);
+
+/* Forward UKF over all steps of every track: writes fwd_mean, fwd_cov, status. */
+int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream);
+
+/* Unscented RTS smoother: reads fwd_mean/fwd_cov, writes sm_mean/sm_cov, ORs status. */
+int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream);
+
+/* Forward then backward on the same stream. */
+int ste_ukf_urtss_f64(const ste_ukf_batch_f64* b, void* stream);
+
+/*
+ * Great-circle process model on `count` independent states.
+ * x, out: [4][count]; dt, sog_rate, cog_rate: [count].
+ */
+int ste_geodetic_dynamics_f64(int64_t count, const double* x, const double* dt, const double* sog_rate,
+                              const double* cog_rate, double* out, void* stream);
+
+/*
+ * Sigma fans of `count` (x, P) pairs: out[j][c][i] for sigma point j in 0..8, component c, pair i.
+ * x: [4][count]; P: [16][count]; out: [9][4][count].  scale = n/(1-W0) (n when weights were never computed).
+ */
+int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double scale, double* out, void* stream);
+
+/*
+ * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
+ *   0 = library default, 1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
+ * Returns the previous value.  Process-global; not part of the reference-facing surface.
+ */
+int ste_set_lanes_per_track(int lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STE_H */

@@ -1,0 +1,581 @@
+// ste_kernels.hip — batched UKF forward pass and unscented RTS smoother for gfx950 (MI355X), plus the C ABI of
+// include/ste.h.  fp64 throughout; no MFMA (4x4 contractions), no LDS: the whole per-track state lives in VGPRs.
+//
+// Lane mapping "L1": one lane per track, 64 tracks per wave, one wave per workgroup so that the (few) waves of a
+// 10k-track batch spread over all 256 CUs.  All per-step inputs/outputs are SoA with the track index fastest, so a
+// wave's accesses are 512-byte contiguous runs.
+//
+// Reference semantics (paths relative to /root/reference/src/track_estimators/kalman_filters/):
+//   forward  : kalman_filter.py:61-117 (driver), unscented.py:178-207 (predict), :219-265 (update)
+//   backward : unscented.py:285-351 (rts_step)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ste.h"
+#include "ste_math.h"
+
+namespace ste {
+
+struct KParams {
+    int B, Nmax, Tmax;
+    unsigned flags;
+    double fan_scale, w0, wi;
+    double H[16], Q[16], R[16];
+    const int32_t* nsteps;
+    const double* x0;
+    const double* P0;
+    const double* dt;
+    const double* sog_rate;
+    const double* cog_rate;
+    const double* sog_rate_rts;
+    const double* cog_rate_rts;
+    const int32_t* upd_idx;
+    const double* z;
+    const double* noise_pred;
+    const double* noise_upd;
+    const double* noise_rts;
+    double* fwd_mean;
+    double* fwd_cov;
+    double* sm_mean;
+    double* sm_cov;
+    int32_t* status;
+};
+
+__device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) M[r][c] = base[(row * 16 + r * 4 + c) * B + t];
+    }
+}
+__device__ __forceinline__ void store_mat(double* base, size_t row, size_t B, size_t t, const double (&M)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) base[(row * 16 + r * 4 + c) * B + t] = M[r][c];
+    }
+}
+__device__ __forceinline__ void load_vec(const double* base, size_t row, size_t B, size_t t, double (&v)[4]) {
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) v[c] = base[(row * 4 + c) * B + t];
+}
+__device__ __forceinline__ void store_vec(double* base, size_t row, size_t B, size_t t, const double (&v)[4]) {
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) base[(row * 4 + c) * B + t] = v[c];
+}
+
+__device__ __forceinline__ bool all_finite(const double (&x)[4], const double (&P)[4][4]) {
+    double acc = 0.0;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        acc += x[r] * 0.0;
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) acc += P[r][c] * 0.0;
+    }
+    return acc == 0.0;  // inf*0 and nan*0 are NaN
+}
+
+// Sigma fan of (x, P): dev[i] = column i of sqrtm(scale*P) (unscented.py:95-105).  chi_{i+1} = x + dev[i],
+// chi_{i+1+n} = x - dev[i], chi_0 = x.  T is symmetric, so column i == row i.
+__device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)[4][4], double scale,
+                                         double (&sig)[9][4]) {
+    double T[4][4];
+    const int st = sym_sqrt4(P, scale, T);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) sig[0][c] = x[c];
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            sig[1 + i][c] = x[c] + T[c][i];
+            sig[5 + i][c] = x[c] - T[c][i];
+        }
+    }
+    return st;
+}
+
+// sum_j W_j a_j b_j^T  for two sets of 9 deviation vectors.
+template <bool kSym>
+__device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const double (&b)[9][4], double w0, double wi,
+                                               double (&out)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = kSym ? r : 0; c < 4; ++c) {
+            double acc = 0.0;
+            STE_UNROLL
+            for (int j = 1; j < 9; ++j) acc = fma(a[j][r], b[j][c], acc);
+            acc = fma(w0 * a[0][r], b[0][c], wi * acc);
+            out[r][c] = acc;
+            if (kSym) out[c][r] = acc;
+        }
+    }
+}
+
+// UKF predict (unscented.py:178-207).  x, P updated in place.
+__device__ __forceinline__ int ukf_predict(const KParams& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
+                                           double cr, const double* noise, size_t nrow, size_t B, size_t t) {
+    double sig[9][4];
+    const int st = sigma_fan(x, P, p.fan_scale, sig);
+    STE_UNROLL
+    for (int j = 0; j < 9; ++j) {
+        double o[4];
+        geodetic_step(sig[j], dt, sr, cr, o);
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) sig[j][c] = o[c];
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        double acc = 0.0;
+        STE_UNROLL
+        for (int j = 1; j < 9; ++j) acc += sig[j][c];
+        x[c] = fma(p.w0, sig[0][c], p.wi * acc);
+    }
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) x[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    STE_UNROLL
+    for (int j = 0; j < 9; ++j) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) sig[j][c] -= x[c];
+    }
+    weighted_outer<true>(sig, sig, p.w0, p.wi, P);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) P[r][c] += p.Q[r * 4 + c];
+    }
+    return st;
+}
+
+// Linear Kalman update with pseudo-inverse gain and Joseph-form covariance (unscented.py:219-265).
+__device__ __forceinline__ int ukf_update(const KParams& p, double (&x)[4], double (&P)[4][4], const double (&zin)[4],
+                                          const double* noise, size_t nrow, size_t B, size_t t) {
+    double H[4][4], R[4][4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            H[r][c] = p.H[r * 4 + c];
+            R[r][c] = p.R[r * 4 + c];
+        }
+    }
+    double z[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) z[c] = zin[c];
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    double HP[4][4], S[4][4], Si[4][4], PHt[4][4], K[4][4];
+    mm(H, P, HP);
+    mmt(HP, H, S);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) S[r][c] += R[r][c];
+    }
+    const int st = sym_pinv4(S, Si);
+    mmt(P, H, PHt);
+    mm(PHt, Si, K);
+    double y[4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        double hx = H[r][0] * x[0];
+        STE_UNROLL
+        for (int c = 1; c < 4; ++c) hx = fma(H[r][c], x[c], hx);
+        y[r] = z[r] - hx;
+    }
+    y[3] = wrap180(y[3]);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        double acc = x[r];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) acc = fma(K[r][c], y[c], acc);
+        x[r] = acc;
+    }
+    x[3] = floored_mod(x[3], 360.0);
+    double A[4][4], AP[4][4], KR[4][4], P1[4][4], P2[4][4];
+    mm(K, H, A);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) A[r][c] = ((r == c) ? 1.0 : 0.0) - A[r][c];
+    }
+    mm(A, P, AP);
+    mmt_sym(AP, A, P1);
+    mm(K, R, KR);
+    mmt_sym(KR, K, P2);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) P[r][c] = P1[r][c] + P2[r][c];
+    }
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward pass, one lane per track
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
+    const size_t B = (size_t)p.B;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+
+    double x[4], P[4][4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) x[c] = p.x0[c * B + t];
+    if (p.flags & STE_FLAG_SHARED_P0) {
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) P[r][c] = p.P0[r * 4 + c];
+        }
+    } else {
+        load_mat(p.P0, 0, B, t, P);
+    }
+    // slot 0 = prior (kalman_filter.py:76-77)
+    store_vec(p.fwd_mean, 0, B, t, x);
+    store_mat(p.fwd_cov, 0, B, t, P);
+
+    int st = 0;
+    if (!(p.flags & STE_FLAG_NO_INITIAL_UPDATE)) {
+        double z0[4];
+        load_vec(p.z, 0, B, t, z0);
+        st |= ukf_update(p, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+    }
+
+    // inputs of step 0
+    double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
+    int ui_n = -1;
+    if (ns > 0) {
+        dt_n = p.dt[t];
+        sr_n = p.sog_rate[t];
+        cr_n = p.cog_rate[t];
+        ui_n = p.upd_idx[t];
+    }
+    for (int k = 0; k < p.Nmax; ++k) {
+        const bool live = k < ns;
+        if (!__any(live)) break;
+        if (live) {
+            const double dt = dt_n, sr = sr_n, cr = cr_n;
+            const int ui = ui_n;
+            // observation for this step's update: address known now, used after the predict
+            double zk[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ui >= 0) load_vec(p.z, (size_t)ui, B, t, zk);
+            // inputs of step k+1: in flight during this step's arithmetic
+            if (k + 1 < ns) {
+                const size_t o = (size_t)(k + 1) * B + t;
+                dt_n = p.dt[o];
+                sr_n = p.sog_rate[o];
+                cr_n = p.cog_rate[o];
+                ui_n = p.upd_idx[o];
+            }
+            st |= ukf_predict(p, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t);
+            if (ui >= 0) st |= ukf_update(p, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
+            store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
+        }
+    }
+    if (!all_finite(x, P)) st |= STE_STATUS_NAN;
+    p.status[t] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// URTSS backward pass, one lane per track (unscented.py:285-351)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
+    const size_t B = (size_t)p.B;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    const double* srp = p.sog_rate_rts ? p.sog_rate_rts : p.sog_rate;
+    const double* crp = p.cog_rate_rts ? p.cog_rate_rts : p.cog_rate;
+
+    // row ns: smoothed = filtered
+    double xs[4], Ps[4][4];
+    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
+    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+
+    // filtered row of the first step to process, prefetched
+    double xn[4] = {0, 0, 0, 0}, Pn[4][4] = {};
+    double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
+    if (ns > 0) {
+        load_vec(p.fwd_mean, (size_t)ns - 1, B, t, xn);
+        load_mat(p.fwd_cov, (size_t)ns - 1, B, t, Pn);
+        const size_t o = (size_t)(ns - 1) * B + t;
+        dt_n = p.dt[o];
+        sr_n = srp[o];
+        cr_n = crp[o];
+    }
+    int st = 0;
+    for (int k = p.Nmax - 1; k >= 0; --k) {
+        if (!__any(k < ns)) continue;  // ragged batch: nobody in this wave has reached its last step yet
+        if (k < ns) {
+            double xk[4], Pk[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                xk[r] = xn[r];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) Pk[r][c] = Pn[r][c];
+            }
+            const double dt = dt_n, sr = sr_n, cr = cr_n;
+            if (k > 0) {
+                load_vec(p.fwd_mean, (size_t)k - 1, B, t, xn);
+                load_mat(p.fwd_cov, (size_t)k - 1, B, t, Pn);
+                const size_t o = (size_t)(k - 1) * B + t;
+                dt_n = p.dt[o];
+                sr_n = srp[o];
+                cr_n = crp[o];
+            }
+            double sig0[9][4], sig[9][4];
+            st |= sigma_fan(xk, Pk, p.fan_scale, sig0);
+            STE_UNROLL
+            for (int j = 0; j < 9; ++j) geodetic_step(sig0[j], dt, sr, cr, sig[j]);
+            double xb[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                double acc = 0.0;
+                STE_UNROLL
+                for (int j = 1; j < 9; ++j) acc += sig[j][c];
+                xb[c] = fma(p.w0, sig[0][c], p.wi * acc);
+            }
+            if (p.noise_rts) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) xb[c] += p.noise_rts[((size_t)k * 4 + c) * B + t];
+            }
+            // P_b is centred on the filtered mean x_k, not on x_b (unscented.py:324-325)
+            double dk[9][4], db[9][4];
+            STE_UNROLL
+            for (int j = 0; j < 9; ++j) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) {
+                    dk[j][c] = sig[j][c] - xk[c];
+                    db[j][c] = sig[j][c] - xb[c];
+                    sig0[j][c] -= xk[c];
+                }
+            }
+            double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
+            weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) Pb[r][c] += p.Q[r * 4 + c];
+            }
+            weighted_outer<false>(sig0, db, p.w0, p.wi, D);  // unscented.py:328-330
+            st |= sym_pinv4(Pb, Pbi);
+            mm(D, Pbi, K);  // unscented.py:333
+            double y[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) y[c] = xs[c] - xb[c];
+            y[3] = wrap180(y[3]);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                double acc = xk[r];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) acc = fma(K[r][c], y[c], acc);
+                xs[r] = acc;
+            }
+            xs[3] = floored_mod(xs[3], 360.0);
+            double dP[4][4], KdP[4][4], U[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) dP[r][c] = Ps[r][c] - Pb[r][c];
+            }
+            mm(K, dP, KdP);
+            mmt_sym(KdP, K, U);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) Ps[r][c] = Pk[r][c] + U[r][c];
+            }
+            store_vec(p.sm_mean, (size_t)k, B, t, xs);
+            store_mat(p.sm_cov, (size_t)k, B, t, Ps);
+        }
+    }
+    if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
+    p.status[t] |= st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// single-function kernels (fine-grained API parity: geodetic_dynamics, compute_sigma_points)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void geodetic_kernel(size_t count, const double* x, const double* dt,
+                                                      const double* sr, const double* cr, double* out) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double xi[4], o[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xi[c] = x[c * count + i];
+    geodetic_step(xi, dt[i], sr[i], cr[i], o);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) out[c * count + i] = o[c];
+}
+
+__global__ __launch_bounds__(64) void sigma_points_kernel(size_t count, const double* x, const double* P,
+                                                          double scale, double* out) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double xi[4], Pi[4][4], sig[9][4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xi[c] = x[c * count + i];
+    load_mat(P, 0, count, i, Pi);
+    sigma_fan(xi, Pi, scale, sig);
+    STE_UNROLL
+    for (int j = 0; j < 9; ++j) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) out[((size_t)j * 4 + c) * count + i] = sig[j][c];
+    }
+}
+
+}  // namespace ste
+
+// ===============================================================================================================
+// C ABI
+// ===============================================================================================================
+namespace {
+
+thread_local char g_err[512] = "";
+int g_lanes_per_track = 0;
+
+int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return STE_OK;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return STE_ELAUNCH;
+}
+
+int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, ste::KParams* kp) {
+    if (!b) return fail(STE_EINVAL, "batch pointer is NULL");
+    if (b->n != 4) return fail(STE_EINVAL, "state dimension n must be 4 (heading index 3 is hard-wired, unscented.py:250)");
+    if (b->B <= 0) return fail(STE_EINVAL, "B must be > 0");
+    if (b->Nmax < 0) return fail(STE_EINVAL, "Nmax must be >= 0");
+    if (b->Tmax < 1) return fail(STE_EINVAL, "Tmax must be >= 1");
+    if (!b->H || !b->Q || !b->R) return fail(STE_EINVAL, "H, Q and R (host 4x4) are required");
+    if (!b->x0 || !b->P0) return fail(STE_EINVAL, "x0 and P0 are required");
+    if (b->Nmax > 0 && (!b->dt || !b->sog_rate || !b->cog_rate || !b->upd_idx))
+        return fail(STE_EINVAL, "dt, sog_rate, cog_rate and upd_idx are required when Nmax > 0");
+    if (!b->z) return fail(STE_EINVAL, "z is required");
+    if (!b->fwd_mean || !b->fwd_cov || !b->status) return fail(STE_EINVAL, "fwd_mean, fwd_cov and status are required");
+    if (need_sm_out && (!b->sm_mean || !b->sm_cov)) return fail(STE_EINVAL, "sm_mean and sm_cov are required");
+    (void)need_fwd_in;
+    kp->B = b->B;
+    kp->Nmax = b->Nmax;
+    kp->Tmax = b->Tmax;
+    kp->flags = b->flags;
+    kp->fan_scale = b->fan_scale;
+    kp->w0 = b->w0;
+    kp->wi = b->wi;
+    memcpy(kp->H, b->H, sizeof(double) * 16);
+    memcpy(kp->Q, b->Q, sizeof(double) * 16);
+    memcpy(kp->R, b->R, sizeof(double) * 16);
+    kp->nsteps = b->nsteps;
+    kp->x0 = b->x0;
+    kp->P0 = b->P0;
+    kp->dt = b->dt;
+    kp->sog_rate = b->sog_rate;
+    kp->cog_rate = b->cog_rate;
+    kp->sog_rate_rts = b->sog_rate_rts;
+    kp->cog_rate_rts = b->cog_rate_rts;
+    kp->upd_idx = b->upd_idx;
+    kp->z = b->z;
+    kp->noise_pred = b->noise_pred;
+    kp->noise_upd = b->noise_upd;
+    kp->noise_rts = b->noise_rts;
+    kp->fwd_mean = b->fwd_mean;
+    kp->fwd_cov = b->fwd_cov;
+    kp->sm_mean = b->sm_mean;
+    kp->sm_cov = b->sm_cov;
+    kp->status = b->status;
+    return STE_OK;
+}
+
+int launch_forward(const ste::KParams& kp, hipStream_t s) {
+    const unsigned grid = (unsigned)((kp.B + 63) / 64);
+    hipLaunchKernelGGL(ste::ukf_forward_l1, dim3(grid), dim3(64), 0, s, kp);
+    return check_hip(hipGetLastError(), "ukf_forward launch");
+}
+
+int launch_backward(const ste::KParams& kp, hipStream_t s) {
+    const unsigned grid = (unsigned)((kp.B + 63) / 64);
+    hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
+    return check_hip(hipGetLastError(), "urtss_backward launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ste_version(void) { return STE_VERSION; }
+
+const char* ste_last_error(void) { return g_err; }
+
+int ste_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ste_set_lanes_per_track(int lanes) {
+    const int prev = g_lanes_per_track;
+    g_lanes_per_track = lanes;
+    return prev;
+}
+
+int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream) {
+    ste::KParams kp;
+    int rc = make_params(b, false, false, &kp);
+    if (rc) return rc;
+    return launch_forward(kp, (hipStream_t)stream);
+}
+
+int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream) {
+    ste::KParams kp;
+    int rc = make_params(b, true, true, &kp);
+    if (rc) return rc;
+    return launch_backward(kp, (hipStream_t)stream);
+}
+
+int ste_ukf_urtss_f64(const ste_ukf_batch_f64* b, void* stream) {
+    ste::KParams kp;
+    int rc = make_params(b, false, true, &kp);
+    if (rc) return rc;
+    rc = launch_forward(kp, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_backward(kp, (hipStream_t)stream);
+}
+
+int ste_geodetic_dynamics_f64(int64_t count, const double* x, const double* dt, const double* sog_rate,
+                              const double* cog_rate, double* out, void* stream) {
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !dt || !sog_rate || !cog_rate || !out) return fail(STE_EINVAL, "NULL pointer argument");
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::geodetic_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, x, dt,
+                       sog_rate, cog_rate, out);
+    return check_hip(hipGetLastError(), "geodetic_dynamics launch");
+}
+
+int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double scale, double* out, void* stream) {
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !P || !out) return fail(STE_EINVAL, "NULL pointer argument");
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::sigma_points_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, x, P,
+                       scale, out);
+    return check_hip(hipGetLastError(), "sigma_points launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// ste_math.h — per-lane fp64 building blocks of the UKF / URTSS kernels (gfx950).
+//
+// Everything here works on small fixed-size arrays whose indices are compile-time constants after unrolling, so the
+// whole filter state lives in VGPRs (no scratch, no LDS).  Reference semantics being reproduced are cited per function
+// (paths relative to /root/reference/src/track_estimators/kalman_filters/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ste {
+
+constexpr double kEarthRadius = 6378.137;              // constants.py:1
+constexpr double kDeg2Rad = 0.017453292519943295;      // NumPy's NPY_PI / 180.0 (np.radians)
+constexpr double kRad2Deg = 57.29577951308232;         // 180.0 / NPY_PI          (np.degrees)
+constexpr double kPinvRcond = 1e-15;                   // np.linalg.pinv default rcond (unscented.py:243,333)
+constexpr int kMaxSweeps = 12;
+// A rotation is skipped when a_pq^2 <= kRotTol2 * |a_pp * a_qq| (relative, Demmel–Veselić style criterion):
+// it would change neither diagonal entry in fp64.  An exactly zero a_pq is always skipped.
+constexpr double kRotTol2 = 4.930380657631324e-32;     // (2^-52)^2
+
+#define STE_UNROLL _Pragma("unroll")
+
+// NumPy floored modulo for a positive divisor (unscented.py:250,257,340,346): fmod, then shift negatives up by b,
+// and an exact zero takes the sign of b (npy_divmod).
+__device__ __forceinline__ double floored_mod(double a, double b) {
+    double r = fmod(a, b);
+    if (r != 0.0) {
+        if (r < 0.0) r += b;
+    } else {
+        r = 0.0;  // copysign(0, b) with b > 0; NaN stays NaN through the other branch
+    }
+    return r;
+}
+
+// (y + 180) % 360 - 180   (unscented.py:250, :340)
+__device__ __forceinline__ double wrap180(double y) { return floored_mod(y + 180.0, 360.0) - 180.0; }
+
+// Great-circle dead reckoning of one state (non_linear_process.py:46-85, c = None).
+__device__ __forceinline__ void geodetic_step(const double (&x)[4], double dt, double sog_rate, double cog_rate,
+                                              double (&out)[4]) {
+    const double lon = x[0] * kDeg2Rad;
+    const double lat = x[1] * kDeg2Rad;
+    const double u = x[2];
+    const double alpha = x[3] * kDeg2Rad;
+    const double udt_r = u * dt / kEarthRadius;
+    double sd, cd, sa, ca, sp, cp;
+    sincos(udt_r, &sd, &cd);
+    sincos(alpha, &sa, &ca);
+    sincos(lat, &sp, &cp);
+    const double term_a = sd * sa;
+    const double term_b = cp * cd - sp * sd * ca;
+    out[0] = (lon + atan2(term_a, term_b)) * kRad2Deg;
+    out[1] = asin(sp * cd + cp * sd * ca) * kRad2Deg;
+    out[2] = u + sog_rate * dt;
+    out[3] = alpha * kRad2Deg + cog_rate * dt;
+}
+
+// One Jacobi rotation on the (P,Q) plane of the symmetric A (both triangles kept), accumulating into V.
+template <int P, int Q>
+__device__ __forceinline__ bool jacobi_rot(double (&A)[4][4], double (&V)[4][4]) {
+    const double apq = A[P][Q];
+    const double app = A[P][P], aqq = A[Q][Q];
+    const bool go = apq * apq > kRotTol2 * fabs(app * aqq);  // false for NaN and for apq == 0
+    if (go) {
+        const double delta = aqq - app;
+        const double hyp = sqrt(delta * delta + 4.0 * apq * apq);
+        double t = 2.0 * apq / (fabs(delta) + hyp);
+        t = delta < 0.0 ? -t : t;
+        const double c = 1.0 / sqrt(1.0 + t * t);
+        const double s = t * c;
+        const double tau = s / (1.0 + c);
+        A[P][P] = app - t * apq;
+        A[Q][Q] = aqq + t * apq;
+        A[P][Q] = 0.0;
+        A[Q][P] = 0.0;
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            if (r != P && r != Q) {
+                const double arp = A[r][P], arq = A[r][Q];
+                const double np_ = arp - s * (arq + tau * arp);
+                const double nq_ = arq + s * (arp - tau * arq);
+                A[r][P] = np_;
+                A[P][r] = np_;
+                A[r][Q] = nq_;
+                A[Q][r] = nq_;
+            }
+        }
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            const double vrp = V[r][P], vrq = V[r][Q];
+            V[r][P] = vrp - s * (vrq + tau * vrp);
+            V[r][Q] = vrq + s * (vrp - tau * vrq);
+        }
+    }
+    return go;
+}
+
+// Cyclic Jacobi eigen-decomposition of a symmetric 4x4: A = V diag(w) V^T.  A is destroyed.
+// Returns false if the sweep cap was hit.  The wave leaves the loop together (__any), but each lane's rotations are
+// gated by its own data only, so a track's result does not depend on which tracks share its wave.
+__device__ __forceinline__ bool jacobi_eig4(double (&A)[4][4], double (&V)[4][4], double (&w)[4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+    bool rotated = true;
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        rotated = jacobi_rot<0, 1>(A, V);
+        rotated |= jacobi_rot<0, 2>(A, V);
+        rotated |= jacobi_rot<0, 3>(A, V);
+        rotated |= jacobi_rot<1, 2>(A, V);
+        rotated |= jacobi_rot<1, 3>(A, V);
+        rotated |= jacobi_rot<2, 3>(A, V);
+        if (!__any(rotated)) break;
+    }
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) w[i] = A[i][i];
+    return !rotated;
+}
+
+// out = V diag(f) V^T (symmetric, upper triangle computed and mirrored).
+__device__ __forceinline__ void recompose(const double (&V)[4][4], const double (&f)[4], double (&out)[4][4]) {
+    double Vf[4][4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int i = 0; i < 4; ++i) Vf[r][i] = V[r][i] * f[i];
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            double acc = Vf[r][0] * V[c][0];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(Vf[r][i], V[c][i], acc);
+            out[r][c] = acc;
+            out[c][r] = acc;
+        }
+    }
+}
+
+// Principal square root of (scale * P) with negative eigenvalues clamped: the real part of scipy.linalg.sqrtm on a
+// symmetric matrix (unscented.py:95-97).  P is symmetrised first.  Returns status bits.
+__device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, double (&T)[4][4]) {
+    double A[4][4], V[4][4], w[4], f[4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            const double v = scale * (0.5 * (P[r][c] + P[c][r]));
+            A[r][c] = v;
+            A[c][r] = v;
+        }
+    }
+    int st = 0;
+    double wmax = 0.0;
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) wmax = fmax(wmax, fabs(A[i][i]));
+    if (!jacobi_eig4(A, V, w)) st |= 0x4;
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        if (w[i] < -1e-12 * wmax) st |= 0x2;
+        f[i] = sqrt(fmax(w[i], 0.0));
+    }
+    recompose(V, f, T);
+    return st;
+}
+
+// Moore–Penrose pseudo-inverse of a symmetric 4x4 with NumPy's cutoff: singular values (= |eigenvalues|) not larger
+// than rcond * max are dropped (np.linalg.pinv as called at unscented.py:243 and :333).
+__device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4][4]) {
+    double A[4][4], V[4][4], w[4], f[4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            const double v = 0.5 * (S[r][c] + S[c][r]);
+            A[r][c] = v;
+            A[c][r] = v;
+        }
+    }
+    int st = 0;
+    if (!jacobi_eig4(A, V, w)) st |= 0x4;
+    double smax = 0.0;
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) smax = fmax(smax, fabs(w[i]));
+    const double cutoff = kPinvRcond * smax;
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) f[i] = (fabs(w[i]) > cutoff) ? 1.0 / w[i] : 0.0;
+    recompose(V, f, Si);
+    return st;
+}
+
+// C = A * B (4x4)
+__device__ __forceinline__ void mm(const double (&A)[4][4], const double (&B)[4][4], double (&C)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            double acc = A[r][0] * B[0][c];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(A[r][i], B[i][c], acc);
+            C[r][c] = acc;
+        }
+    }
+}
+
+// C = A * B^T (4x4)
+__device__ __forceinline__ void mmt(const double (&A)[4][4], const double (&B)[4][4], double (&C)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            double acc = A[r][0] * B[c][0];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(A[r][i], B[c][i], acc);
+            C[r][c] = acc;
+        }
+    }
+}
+
+// C = sym(A * B^T): upper triangle computed, mirrored (used where the product is symmetric by construction).
+__device__ __forceinline__ void mmt_sym(const double (&A)[4][4], const double (&B)[4][4], double (&C)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            double acc = A[r][0] * B[c][0];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(A[r][i], B[c][i], acc);
+            C[r][c] = acc;
+            C[c][r] = acc;
+        }
+    }
+}
+
+}  // namespace ste

@@ -1,0 +1,113 @@
+"""
+ctypes binding of the C ABI declared in include/ste.h (libste_hip.so, built in-tree by ``__graft_entry__.build()``).
+
+There is deliberately no CPU fallback: if the shared library is missing, or no MI355X is visible when a compute entry
+point is called, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))  # .../ship-track-estimators_amd
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libste_hip.so")
+
+STE_FLAG_SHARED_P0 = 0x1
+STE_FLAG_NO_INITIAL_UPDATE = 0x2
+
+STE_STATUS_NAN = 0x1
+STE_STATUS_CLAMPED = 0x2
+STE_STATUS_NOCONV = 0x4
+
+_dp = C.c_void_p  # device / host pointers travel as integers
+
+
+class SteUkfBatchF64(C.Structure):
+    """Mirror of ``struct ste_ukf_batch_f64`` (include/ste.h)."""
+
+    _fields_ = [
+        ("B", C.c_int32),
+        ("Nmax", C.c_int32),
+        ("Tmax", C.c_int32),
+        ("n", C.c_int32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_int32),
+        ("fan_scale", C.c_double),
+        ("w0", C.c_double),
+        ("wi", C.c_double),
+        ("H", _dp),
+        ("Q", _dp),
+        ("R", _dp),
+        ("nsteps", _dp),
+        ("x0", _dp),
+        ("P0", _dp),
+        ("dt", _dp),
+        ("sog_rate", _dp),
+        ("cog_rate", _dp),
+        ("sog_rate_rts", _dp),
+        ("cog_rate_rts", _dp),
+        ("upd_idx", _dp),
+        ("z", _dp),
+        ("noise_pred", _dp),
+        ("noise_upd", _dp),
+        ("noise_rts", _dp),
+        ("fwd_mean", _dp),
+        ("fwd_cov", _dp),
+        ("sm_mean", _dp),
+        ("sm_cov", _dp),
+        ("status", _dp),
+    ]
+
+
+# every symbol include/ste.h declares: (restype, argtypes)
+SYMBOLS = {
+    "ste_version": (C.c_int, []),
+    "ste_last_error": (C.c_char_p, []),
+    "ste_device_count": (C.c_int, []),
+    "ste_ukf_forward_f64": (C.c_int, [C.POINTER(SteUkfBatchF64), C.c_void_p]),
+    "ste_urtss_backward_f64": (C.c_int, [C.POINTER(SteUkfBatchF64), C.c_void_p]),
+    "ste_ukf_urtss_f64": (C.c_int, [C.POINTER(SteUkfBatchF64), C.c_void_p]),
+    "ste_geodetic_dynamics_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
+    "ste_sigma_points_f64": (C.c_int, [C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
+    "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
+}
+
+
+class SteError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libste_hip.so (once) and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SteError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "from the repo root (hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ste_last_error()
+        raise SteError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    lib = load()
+    if lib.ste_device_count() < 1:
+        raise SteError("no HIP device visible: the UKF/URTSS path runs only on an MI355X (gfx950); no CPU fallback")
+    return lib

@@ -1,0 +1,311 @@
+"""
+Batched UKF + URTSS over many independent ship tracks on one MI355X.
+
+This is the host side of the hot path: it turns B ``ShipTrack``-like objects into the structure-of-arrays batch
+that include/ste.h describes (track index fastest), precomputes the per-step update schedule with the same float
+accumulation the reference driver performs (kalman_filter.py:73,98-102), launches the HIP kernels through the C ABI
+and hands back per-track histories shaped like the reference's return values.
+
+PyTorch is used only for device memory and streams.  There is no CPU fallback.
+
+Reference call sites replaced (relative to /root/reference):
+  examples/example_ukf_rts_smoother_batch.py:19-90   the per-ship Python loop -> one batched launch
+  src/track_estimators/kalman_filters/kalman_filter.py:36-137   run / run_rts_smoother
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ._hip import binding
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# host-side logic (pure NumPy, no arithmetic of the filter itself)
+# ----------------------------------------------------------------------------------------------------------------
+def sigma_constants(n: int, weights_computed: bool = True):
+    """(fan_scale, w0, wi) as unscented.py:95,125,132 computes them in Python floats."""
+    w0 = 1 - n / 3.0
+    wi = (1 - w0) / (2 * n)
+    fan_scale = n / (1 - (w0 if weights_computed else 0.0))
+    return fan_scale, w0, wi
+
+
+def update_schedule(dt, dts, t0=0):
+    """
+    Float-equality update trigger of the reference driver (kalman_filter.py:73,98-102), precomputed.
+
+    Returns ``upd_idx`` (int32[N]: observation column consumed after step k, -1 = none), ``rate_idx`` (int64[N]:
+    index into sog_rate/cog_rate that predict uses at step k, kalman_filter.py:93-94) and the final time.
+    The running time is accumulated by sequential float addition exactly like ``self.time += dt``.
+    """
+    dt = np.asarray(dt, dtype=np.float64)
+    cums = np.cumsum(np.asarray(dts, dtype=np.float64))
+    times = np.cumsum(np.concatenate([[np.float64(t0)], dt]))[1:]
+    fires = np.isin(times, cums)
+    after = np.cumsum(fires)
+    upd_idx = np.where(fires, after, -1).astype(np.int32)
+    rate_idx = after - fires
+    return upd_idx, rate_idx, (times[-1] if len(times) else np.float64(t0))
+
+
+def rts_rate_index(nrows: int, dts_len: int, T: int) -> np.ndarray:
+    """Index into the length-T rate arrays read by the smoother at step k (unscented.py:287-292, 310-311)."""
+    rep = int(nrows / dts_len)
+    idx = np.repeat(np.arange(T), rep)
+    if len(idx) < nrows - 1:
+        raise IndexError(
+            f"smoother rate expansion too short: np.repeat(rate[{T}], {rep}) has {len(idx)} entries for {nrows - 1} steps"
+        )
+    return idx[: nrows - 1]
+
+
+@dataclasses.dataclass
+class HostBatch:
+    """NumPy image of ``struct ste_ukf_batch_f64``; arrays are C-contiguous with the track index last."""
+
+    B: int
+    Nmax: int
+    Tmax: int
+    H: np.ndarray
+    Q: np.ndarray
+    R: np.ndarray
+    nsteps: np.ndarray  # (B,) int32
+    x0: np.ndarray  # (4, B)
+    P0: np.ndarray  # (16,) shared or (16, B)
+    dt: np.ndarray  # (Nmax, B)
+    sog_rate: np.ndarray
+    cog_rate: np.ndarray
+    sog_rate_rts: Optional[np.ndarray]
+    cog_rate_rts: Optional[np.ndarray]
+    upd_idx: np.ndarray  # (Nmax, B) int32
+    z: np.ndarray  # (Tmax, 4, B)
+    noise_pred: Optional[np.ndarray] = None  # (Nmax, 4, B)
+    noise_upd: Optional[np.ndarray] = None  # (Nmax+1, 4, B)
+    noise_rts: Optional[np.ndarray] = None  # (Nmax, 4, B)
+    weights_computed: bool = True
+    initial_update: bool = True
+
+    @property
+    def shared_p0(self) -> bool:
+        return self.P0.ndim == 1
+
+    @property
+    def track_steps(self) -> int:
+        return int(self.nsteps.sum())
+
+
+def _as44(M, name):
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64))
+    if M.shape != (4, 4):
+        raise ValueError(f"{name} must be 4x4 for the HIP path (got {M.shape}); the reference hard-codes the heading at "
+                         "index 3 (unscented.py:250)")
+    return M
+
+
+def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, R, P0, t0s=None,
+                noise: Optional[Sequence[dict]] = None) -> HostBatch:
+    """
+    Pack B tracks (objects carrying ``z`` (4,T), ``dts`` (T-1,), ``sog_rate`` (T,), ``cog_rate`` (T,) like a
+    reference ``ShipTrack``, ship_track.py:70-83) with their per-track ``dt`` arrays and priors into a HostBatch.
+    Ragged batches are padded to the longest track.  ``P0`` is one 4x4 shared matrix or a sequence of B matrices.
+    ``noise`` (test-only) is a per-track list of dicts with ``noise_pred`` (N,4), ``noise_upd`` (N+1,4), ``noise_rts`` (N,4).
+    """
+    B = len(tracks)
+    if B == 0:
+        raise ValueError("empty batch")
+    H, Q, R = _as44(H, "H"), _as44(Q, "Q"), _as44(R, "R")
+    Ns = [len(d) for d in dts_per_track]
+    Ts = [np.asarray(tr.z).shape[1] for tr in tracks]
+    Nmax, Tmax = max(Ns), max(Ts)
+    nsteps = np.asarray(Ns, dtype=np.int32)
+    x0 = np.zeros((4, B))
+    dt = np.zeros((Nmax, B))
+    sr = np.zeros((Nmax, B))
+    cr = np.zeros((Nmax, B))
+    srr = np.zeros((Nmax, B))
+    crr = np.zeros((Nmax, B))
+    ui = np.full((Nmax, B), -1, dtype=np.int32)
+    z = np.zeros((Tmax, 4, B))
+    P0 = np.asarray(P0, dtype=np.float64)
+    if P0.shape == (4, 4):
+        P0p = np.ascontiguousarray(P0.reshape(16))
+    elif P0.shape == (B, 4, 4):
+        P0p = np.ascontiguousarray(P0.reshape(B, 16).T)
+    else:
+        raise ValueError(f"P0 must be (4,4) or (B,4,4), got {P0.shape}")
+    have_noise = noise is not None
+    npred = np.zeros((Nmax, 4, B)) if have_noise else None
+    nupd = np.zeros((Nmax + 1, 4, B)) if have_noise else None
+    nrts = np.zeros((Nmax, 4, B)) if have_noise else None
+    for b, tr in enumerate(tracks):
+        zb = np.asarray(tr.z, dtype=np.float64)
+        if zb.shape[0] != 4:
+            raise ValueError("measurement matrix z must have 4 rows (lon, lat, sog, cog): call "
+                             "get_measurements(include_sog=True, include_cog=True)")
+        T, N = Ts[b], Ns[b]
+        d = np.asarray(dts_per_track[b], dtype=np.float64)
+        dts = np.asarray(tr.dts, dtype=np.float64)
+        sog_rate = np.asarray(tr.sog_rate, dtype=np.float64)
+        cog_rate = np.asarray(tr.cog_rate, dtype=np.float64)
+        u, ridx, _ = update_schedule(d, dts, 0 if t0s is None else t0s[b])
+        if N and (u.max() >= T or ridx.max() >= len(sog_rate)):
+            raise IndexError("update index runs past the last observation (kalman_filter.py:105)")
+        x0[:, b] = np.asarray(x0s[b], dtype=np.float64).reshape(-1)
+        z[:T, :, b] = zb.T
+        dt[:N, b] = d
+        ui[:N, b] = u
+        sr[:N, b] = sog_rate[ridx]
+        cr[:N, b] = cog_rate[ridx]
+        if N and len(dts):
+            try:
+                rr = rts_rate_index(N + 1, len(dts), len(sog_rate))
+                srr[:N, b] = sog_rate[rr]
+                crr[:N, b] = cog_rate[rr]
+            except IndexError:
+                # only the smoother needs these; surface the reference's IndexError when it is called
+                srr[:N, b] = np.nan
+                crr[:N, b] = np.nan
+        if have_noise:
+            nb = noise[b]
+            npred[:N, :, b] = nb["noise_pred"]
+            nupd[: N + 1, :, b] = nb["noise_upd"]
+            nrts[:N, :, b] = nb["noise_rts"]
+    same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
+    return HostBatch(B=B, Nmax=Nmax, Tmax=Tmax, H=H, Q=Q, R=R, nsteps=nsteps, x0=x0, P0=P0p, dt=dt, sog_rate=sr,
+                     cog_rate=cr, sog_rate_rts=None if same_rts else srr, cog_rate_rts=None if same_rts else crr,
+                     upd_idx=ui, z=z, noise_pred=npred, noise_upd=nupd, noise_rts=nrts)
+
+
+def pack_uniform(sb, substeps: int, H, Q, R, P0) -> HostBatch:
+    """
+    Fast path for a batch where every track has the same number of observations (``synthetic.SyntheticBatch``):
+    vectorised over tracks.  x0 = z[:, 0] (example_ukf_rts_smoother_batch.py:60); dt = generate_dts(dts, substeps).
+    """
+    H, Q, R = _as44(H, "H"), _as44(Q, "Q"), _as44(R, "R")
+    B, T = sb.lon.shape
+    s = int(substeps)
+    N = s * (T - 1)
+    dt = np.repeat(sb.dts / s, s, axis=1)  # (B, N): utils.py:194-198
+    cums = np.cumsum(sb.dts, axis=1)
+    times = np.cumsum(dt, axis=1)  # sequential per row, starting from 0 + dt[0] == dt[0]
+    fires = np.empty((B, N), dtype=bool)
+    for b in range(B):
+        fires[b] = np.isin(times[b], cums[b])
+    after = np.cumsum(fires, axis=1)
+    upd_idx = np.where(fires, after, -1).astype(np.int32)
+    ridx = after - fires
+    if upd_idx.max() >= T:
+        raise IndexError("update index runs past the last observation (kalman_filter.py:105)")
+    ar = np.arange(B)[:, None]
+    sr = sb.sog_rate[ar, ridx]
+    cr = sb.cog_rate[ar, ridx]
+    rr = rts_rate_index(N + 1, T - 1, T)
+    srr = sb.sog_rate[:, rr]
+    crr = sb.cog_rate[:, rr]
+    same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
+    P0 = np.asarray(P0, dtype=np.float64)
+    c = np.ascontiguousarray
+    return HostBatch(
+        B=B, Nmax=N, Tmax=T, H=H, Q=Q, R=R, nsteps=np.full(B, N, dtype=np.int32), x0=c(sb.z[:, :, 0].T),
+        P0=c(P0.reshape(16)), dt=c(dt.T), sog_rate=c(sr.T), cog_rate=c(cr.T),
+        sog_rate_rts=None if same_rts else c(srr.T), cog_rate_rts=None if same_rts else c(crr.T),
+        upd_idx=c(upd_idx.T), z=c(sb.z.transpose(2, 1, 0)),
+    )
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# device side
+# ----------------------------------------------------------------------------------------------------------------
+class DeviceBatch:
+    """A HostBatch resident in HBM plus its output buffers; ``forward`` / ``backward`` / ``run`` launch the kernels."""
+
+    _IN = ("nsteps", "x0", "P0", "dt", "sog_rate", "cog_rate", "sog_rate_rts", "cog_rate_rts", "upd_idx", "z",
+           "noise_pred", "noise_upd", "noise_rts")
+
+    def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True):
+        import torch
+
+        self.lib = binding.require_gpu()
+        self.torch = torch
+        self.hb = hb
+        self.device = torch.device(device)
+        self.t = {}
+        for name in self._IN:
+            a = getattr(hb, name)
+            self.t[name] = None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        B, N = hb.B, hb.Nmax
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.fwd_mean = torch.empty((N + 1, 4, B), **f64)
+        self.fwd_cov = torch.empty((N + 1, 16, B), **f64)
+        self.sm_mean = torch.empty((N + 1, 4, B), **f64) if alloc_smoothed else None
+        self.sm_cov = torch.empty((N + 1, 16, B), **f64) if alloc_smoothed else None
+        self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        fan_scale, w0, wi = sigma_constants(4, hb.weights_computed)
+        self._keep = (hb.H, hb.Q, hb.R)
+        s = binding.SteUkfBatchF64()
+        s.B, s.Nmax, s.Tmax, s.n = B, N, hb.Tmax, 4
+        s.flags = (binding.STE_FLAG_SHARED_P0 if hb.shared_p0 else 0) | (
+            0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE)
+        s.fan_scale, s.w0, s.wi = fan_scale, w0, wi
+        s.H, s.Q, s.R = hb.H.ctypes.data, hb.Q.ctypes.data, hb.R.ctypes.data
+        for name in self._IN:
+            ten = self.t[name]
+            setattr(s, name, None if ten is None else ten.data_ptr())
+        s.fwd_mean, s.fwd_cov = self.fwd_mean.data_ptr(), self.fwd_cov.data_ptr()
+        s.sm_mean = None if self.sm_mean is None else self.sm_mean.data_ptr()
+        s.sm_cov = None if self.sm_cov is None else self.sm_cov.data_ptr()
+        s.status = self.status.data_ptr()
+        self.struct = s
+
+    def _stream(self, stream):
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device)
+        return C.c_void_p(stream.cuda_stream)
+
+    def forward(self, stream=None):
+        binding.check(self.lib.ste_ukf_forward_f64(C.byref(self.struct), self._stream(stream)), "ste_ukf_forward_f64")
+
+    def backward(self, stream=None):
+        binding.check(self.lib.ste_urtss_backward_f64(C.byref(self.struct), self._stream(stream)),
+                      "ste_urtss_backward_f64")
+
+    def run(self, stream=None):
+        binding.check(self.lib.ste_ukf_urtss_f64(C.byref(self.struct), self._stream(stream)), "ste_ukf_urtss_f64")
+
+    # -- results ------------------------------------------------------------------------------------------------
+    def filtered(self):
+        """(means (B, Nmax+1, 4), covs (B, Nmax+1, 4, 4)) as NumPy arrays (rows past nsteps[b] are padding)."""
+        B, N = self.hb.B, self.hb.Nmax
+        m = self.fwd_mean.permute(2, 0, 1).contiguous().cpu().numpy()
+        P = self.fwd_cov.permute(2, 0, 1).contiguous().cpu().numpy().reshape(B, N + 1, 4, 4)
+        return m, P
+
+    def smoothed(self):
+        B, N = self.hb.B, self.hb.Nmax
+        m = self.sm_mean.permute(2, 0, 1).contiguous().cpu().numpy()
+        P = self.sm_cov.permute(2, 0, 1).contiguous().cpu().numpy().reshape(B, N + 1, 4, 4)
+        return m, P
+
+    def status_host(self):
+        return self.status.cpu().numpy()
+
+
+def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True):
+    """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays."""
+    db = DeviceBatch(hb, device=device, alloc_smoothed=smooth)
+    if smooth:
+        if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts).any():
+            raise IndexError("smoother rate expansion too short for at least one track (unscented.py:287-292,310)")
+        db.run()
+    else:
+        db.forward()
+    db.torch.cuda.synchronize(db.device)
+    out = {"status": db.status_host(), "nsteps": hb.nsteps.copy()}
+    out["means"], out["covs"] = db.filtered()
+    if smooth:
+        out["means_smoothed"], out["covs_smoothed"] = db.smoothed()
+    return out

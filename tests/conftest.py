@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_ROOT = os.path.join(ROOT, "ship-track-estimators_amd")
+for p in (ROOT, PKG_ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_cases(name):
+    """Unpack a tests/golden/<name>.npz written by make_golden.pack_cases into a list of dicts."""
+    d = np.load(os.path.join(GOLDEN, name))
+    n = int(d["ncases"])
+    cases = [dict() for _ in range(n)]
+    for key in d.files:
+        if key == "ncases":
+            continue
+        ci, field = key.split("_", 1)
+        v = d[key]
+        cases[int(ci[1:])][field] = v.item() if v.shape == () else v
+    return cases
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

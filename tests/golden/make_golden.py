@@ -1,0 +1,331 @@
+"""
+Generate the golden vectors under tests/golden/ by importing and RUNNING the reference implementation.
+
+Runs only in the build container (needs /root/reference); never on the GPU box.  The committed ``*.npz`` files hold
+data only (inputs + the reference's outputs); nothing of the reference's source travels.
+
+    python tests/golden/make_golden.py
+
+Reference entry points exercised (paths relative to /root/reference/src/track_estimators):
+  kalman_filters/non_linear_process.py:6   geodetic_dynamics
+  kalman_filters/unscented.py:76,109,144,209,267   compute_sigma_points / compute_weights / predict / update / rts_step
+  kalman_filters/unscented.py:389,430,485   robustification helpers (direct calls; their call site is commented out)
+  kalman_filters/kalman_filter.py:36,119   run / run_rts_smoother
+  ship_track.py:107-338   ShipTrack.read_csv / calculate_* / get_measurements (with utils.haversine_formula / heading)
+  utils.py:175            generate_dts
+
+``geographiclib`` is not installed in this image; a stub module is registered before import (the real-data golden
+uses the reference's own pure-NumPy ``haversine_formula``/``heading`` injection instead).
+
+Noise handling: the reference draws from the global unseeded ``np.random.normal`` (unscented.py:198,232,320).
+``zero`` cases patch it to return zeros; ``replay`` cases patch it to draw from a seeded ``RandomState`` and record
+every draw in call order, then re-index the draws per step (the layout the oracle and the HIP kernels consume).
+"""
+import copy
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "ship-track-estimators_amd"))
+
+# --- import the reference --------------------------------------------------------------------------------------
+_m = types.ModuleType("geographiclib")
+_g = types.ModuleType("geographiclib.geodesic")
+
+
+class _Geodesic:  # never called: the goldens inject haversine/heading
+    WGS84 = None
+
+
+_g.Geodesic = _Geodesic
+_m.geodesic = _g
+sys.modules["geographiclib"] = _m
+sys.modules["geographiclib.geodesic"] = _g
+
+REF_SRC = "/root/reference/src"
+# the product package has the same import name; make sure the reference wins in this process
+sys.path.insert(0, REF_SRC)
+import track_estimators as _ref_pkg  # noqa: E402
+
+assert _ref_pkg.__file__.startswith(REF_SRC), _ref_pkg.__file__
+from track_estimators.kalman_filters.non_linear_process import geodetic_dynamics  # noqa: E402
+from track_estimators.kalman_filters.unscented import UnscentedKalmanFilter  # noqa: E402
+from track_estimators.ship_track import ShipTrack  # noqa: E402
+from track_estimators.utils import generate_dts, haversine_formula, heading  # noqa: E402
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    "ste_synthetic", os.path.join(ROOT, "ship-track-estimators_amd", "track_estimators", "synthetic.py")
+)
+synthetic = importlib.util.module_from_spec(_spec)
+sys.modules["ste_synthetic"] = synthetic
+_spec.loader.exec_module(synthetic)
+
+warnings.simplefilter("ignore")
+
+
+class NoisePatch:
+    """Patch np.random.normal: mode 'zero' -> zeros; mode 'replay' -> seeded RandomState, every draw recorded."""
+
+    def __init__(self, mode, seed=0):
+        self.mode = mode
+        self.rs = np.random.RandomState(seed)
+        self.draws = []
+        self._orig = None
+
+    def _normal(self, loc=0.0, scale=1.0, size=None):
+        if self.mode == "zero":
+            out = np.zeros(size)
+        else:
+            out = self.rs.normal(loc=loc, scale=scale, size=size)
+        self.draws.append(np.array(out, dtype=np.float64))
+        return out
+
+    def __enter__(self):
+        self._orig = np.random.normal
+        np.random.normal = self._normal
+        return self
+
+    def __exit__(self, *a):
+        np.random.normal = self._orig
+
+
+def ship_track_from_arrays(sb, i):
+    st = ShipTrack()
+    st.lon, st.lat, st.dts = sb.lon[i].copy(), sb.lat[i].copy(), sb.dts[i].copy()
+    st.sog, st.cog = sb.sog[i].copy(), sb.cog[i].copy()
+    st.sog_rate, st.cog_rate = sb.sog_rate[i].copy(), sb.cog_rate[i].copy()
+    st.z = sb.z[i].copy()
+    return st
+
+
+def run_reference(st, H, Q, R, P, substeps, mode, seed=0):
+    """Run ukf.run + run_rts_smoother of the reference on one ShipTrack; return a dict of arrays."""
+    x0 = st.z[:, 0].reshape(-1, 1).copy()
+    ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
+    dt = generate_dts(st.dts, substeps)
+    N = len(dt)
+    with NoisePatch(mode, seed) as npf:
+        means, covs = ukf.run(nsteps=N, dt=dt, ship_track=st)
+        nfwd = len(npf.draws)
+        st2 = copy.deepcopy(st)  # rts_step mutates its ShipTrack (unscented.py:287-292)
+        sm, sc = ukf.run_rts_smoother(ship_track=st2)
+        draws = npf.draws
+    # re-index the draws per step
+    cums = np.cumsum(st.dts)
+    t = 0
+    fires = np.zeros(N, dtype=bool)
+    for k in range(N):
+        t += dt[k]
+        fires[k] = t in cums
+    n = H.shape[1]
+    noise_pred = np.zeros((N, n))
+    noise_upd = np.zeros((N + 1, n))
+    noise_rts = np.zeros((N, n))
+    it = iter(draws)
+    noise_upd[0] = next(it)
+    for k in range(N):
+        noise_pred[k] = next(it)
+        if fires[k]:
+            noise_upd[k + 1] = next(it)
+    assert nfwd == 1 + N + int(fires.sum())
+    for k in range(N - 1, -1, -1):
+        noise_rts[k] = next(it)
+    assert next(it, None) is None
+    return dict(
+        dt=dt, fires=fires, means=means, covs=covs, means_smoothed=sm, covs_smoothed=sc,
+        noise_pred=noise_pred, noise_upd=noise_upd, noise_rts=noise_rts, x0=x0[:, 0],
+    )
+
+
+def pack_cases(cases):
+    out = {"ncases": np.int64(len(cases))}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            out[f"c{i}_{k}"] = np.asarray(v)
+    return out
+
+
+def synthetic_cases():
+    H, Q, R, P = synthetic.example_matrices()
+    H = np.diag([1, 1, 0, 0])  # int64, as the batch example builds it (example_ukf_rts_smoother_batch.py:43)
+    cases = []
+    # (nobs, gap_h, substeps, seed0, mode) -> N = substeps * (nobs-1)
+    plan = [
+        (126, 1.0, 4, 0, "zero"), (126, 1.0, 4, 1, "zero"),
+        (251, 1.0, 2, 2, "zero"), (501, 1.0, 1, 3, "zero"),
+        (126, 1.0, 4, 4, "replay"), (251, 1.0, 2, 5, "replay"), (501, 1.0, 1, 6, "replay"),
+        # non-dyadic sub-steps: 6.0 h / 10 -> most float-equality triggers are missed (SURVEY headline 5)
+        (21, 6.0, 10, 7, "zero"), (21, 6.0, 10, 8, "replay"),
+        # irregular gaps
+        (40, 1.0, 3, 9, "zero"),
+    ]
+    for nobs, gap, s, seed0, mode in plan:
+        sb = synthetic.make_batch(1, nobs=nobs, gap_h=gap, seed0=seed0)
+        if seed0 == 9:
+            rng = np.random.default_rng(99)
+            sb.dts[0] = rng.choice([0.5, 1.0, 1.5, 3.0], size=nobs - 1)
+        st = ship_track_from_arrays(sb, 0)
+        res = run_reference(st, H, Q, R, P, s, mode, seed=1000 + seed0)
+        res.update(
+            mode=mode, substeps=s, H=H.astype(np.float64), Q=Q, R=R, P0=P,
+            dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0], cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0],
+        )
+        cases.append(res)
+        print(f"synthetic nobs={nobs} s={s} mode={mode}: N={len(res['dt'])} updates={int(res['fires'].sum())}")
+    return cases
+
+
+def edge_cases():
+    """Dense H/R/Q/P, near-pole latitude, heading wrap through 0/360, indefinite prior."""
+    cases = []
+    rng = np.random.default_rng(4242)
+    # (a) dense SPD matrices, H full rank (all four states observed)
+    sb = synthetic.make_batch(1, nobs=31, gap_h=2.0, seed0=21)
+    A = rng.normal(size=(4, 4))
+    P = A @ A.T * 0.05 + np.diag([0.5, 0.5, 0.5, 0.5])
+    Bq = rng.normal(size=(4, 4)) * 1e-2
+    Q = Bq @ Bq.T + np.diag([1e-4, 1e-4, 1e-6, 1e-6])
+    Br = rng.normal(size=(4, 4)) * 0.1
+    R = Br @ Br.T + np.diag([0.05, 0.05, 0.5, 2.0])
+    H = np.eye(4) + 0.05 * rng.normal(size=(4, 4))
+    st = ship_track_from_arrays(sb, 0)
+    res = run_reference(st, H, Q, R, P, 2, "replay", seed=77)
+    res.update(mode="replay", substeps=2, H=H, Q=Q, R=R, P0=P, dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0],
+               cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0])
+    cases.append(res)
+    # (b) high latitude + heading crossing 0/360 repeatedly
+    H, Q, R, P = synthetic.example_matrices()
+    sb = synthetic.make_batch(1, nobs=41, gap_h=1.0, seed0=22)
+    # rebuild the truth at 78N with heading near 359 and a positive turn rate
+    T = 41
+    lon = np.empty(T); lat = np.empty(T); sog = np.full(T, 25.0); cog = np.empty(T)
+    lon[0], lat[0], cog[0] = 10.0, 78.0, 357.0
+    for k in range(T - 1):
+        lo, la = synthetic._advance(lon[k], lat[k], sog[k], cog[k], 1.0)
+        lon[k + 1], lat[k + 1] = lo, la
+        cog[k + 1] = (cog[k] + 1.3) % 360.0
+    on = np.random.default_rng(5).normal(0, 0.02, (2, T))
+    sb.lon[0], sb.lat[0] = lon + on[0], lat + on[1]
+    sb.sog[0], sb.cog[0] = sog, cog
+    sb.sog_rate[0, 1:] = np.diff(sog); sb.sog_rate[0, 0] = 0
+    sb.cog_rate[0, 1:] = np.diff(cog); sb.cog_rate[0, 0] = 0
+    sb.z[0] = np.vstack([sb.lon[0], sb.lat[0], sog, cog])
+    st = ship_track_from_arrays(sb, 0)
+    res = run_reference(st, np.diag([1, 1, 0, 1]), Q, np.diag([0.25, 0.25, 0, 4.0]), P, 4, "zero")
+    res.update(mode="zero", substeps=4, H=np.diag([1.0, 1, 0, 1]), Q=Q, R=np.diag([0.25, 0.25, 0, 4.0]), P0=P,
+               dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0], cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0])
+    cases.append(res)
+    # (c) indefinite prior covariance: sqrtm goes complex, the reference keeps the real part (unscented.py:97-105)
+    sb = synthetic.make_batch(1, nobs=11, gap_h=1.0, seed0=23)
+    Pind = np.diag([1.0, 1.0, -0.5, 1.0])
+    Pind[0, 1] = Pind[1, 0] = 0.3
+    st = ship_track_from_arrays(sb, 0)
+    res = run_reference(st, np.diag([1, 1, 0, 0]), Q, R, Pind, 2, "zero")
+    res.update(mode="zero", substeps=2, H=H, Q=Q, R=R, P0=Pind, dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0],
+               cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0])
+    cases.append(res)
+    for c in cases:
+        print(f"edge: N={len(c['dt'])} finite={np.isfinite(c['means_smoothed']).all()}")
+    return cases
+
+
+def real_case():
+    """Config 1: ship 01203823, input.json matrices, 2 sub-steps, haversine sog/cog (geographiclib absent)."""
+    csv = "/root/reference/data/historical_ships/historical_ship_data.csv"
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv(csv_file=csv, ship_id="01203823", id_col="primary.id", lat_col="lat", lon_col="lon")
+    st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    H = np.diag([1, 1, 0, 0]); R = np.diag([0.001, 0.001, 0, 0])
+    Q = np.diag([1e-2, 1e-2, 1e-4, 1e-4]); P = np.diag([1.0, 1.0, 1.0, 1.0])
+    cases = []
+    for mode in ("zero", "replay"):
+        res = run_reference(copy.deepcopy(st), H, Q, R, P, 2, mode, seed=2024)
+        res.update(mode=mode, substeps=2, H=H.astype(np.float64), Q=Q, R=R.astype(np.float64), P0=P, dts=st.dts,
+                   z=st.z, sog=st.sog, cog=st.cog, sog_rate=st.sog_rate, cog_rate=st.cog_rate, lon=st.lon, lat=st.lat)
+        cases.append(res)
+        print(f"ship 01203823 mode={mode}: T={len(st.lon)} N={len(res['dt'])}")
+    return cases
+
+
+def kats():
+    """Per-function known answers."""
+    rng = np.random.default_rng(7)
+    out = {}
+    # geodetic_dynamics
+    X = np.column_stack([rng.uniform(-180, 180, 64), rng.uniform(-85, 85, 64), rng.uniform(0, 60, 64),
+                         rng.uniform(-30, 400, 64)])
+    dts = rng.choice([0.25, 0.5, 1.0, 6.0, 12.5, -1.0], 64)
+    sr = rng.normal(0, 0.05, 64); cr = rng.normal(0, 0.5, 64)
+    Y = np.array([geodetic_dynamics(X[i], None, dts[i], sr[i], cr[i]) for i in range(64)])
+    out.update(gd_x=X, gd_dt=dts, gd_sr=sr, gd_cr=cr, gd_y=Y)
+    # sigma points (weights set, and weights never computed -> W[0,0]=0 branch), weights
+    Ps, xs, sig_w, sig_now = [], [], [], []
+    for i in range(16):
+        A = rng.normal(size=(4, 4)); P = A @ A.T * rng.choice([1e-4, 1e-2, 1.0]) + np.diag([1e-5, 1e-5, 1e-3, 1e-3])
+        x = rng.normal(size=4) * 10
+        u = UnscentedKalmanFilter(H=np.eye(4), P=P, x0=x)
+        sig_now.append(u.compute_sigma_points().copy())
+        u.compute_weights()
+        sig_w.append(u.compute_sigma_points().copy())
+        Ps.append(P); xs.append(x)
+    u = UnscentedKalmanFilter(H=np.eye(4))
+    out.update(sp_P=np.array(Ps), sp_x=np.array(xs), sp_sig_weighted=np.array(sig_w), sp_sig_unweighted=np.array(sig_now),
+               weights4=u.compute_weights().copy())
+    u2 = UnscentedKalmanFilter(H=np.eye(2))
+    out.update(weights2=u2.compute_weights().copy())
+    # single predict / update calls
+    H, Q, R, P0 = synthetic.example_matrices()
+    px, pP, pdt, psr, pcr, pxo, pPo, uz, uxo, uPo = ([] for _ in range(10))
+    with NoisePatch("zero"):
+        for i in range(16):
+            A = rng.normal(size=(4, 4)) * 0.1; P = A @ A.T + np.diag([1e-3, 1e-3, 1e-2, 1e-2])
+            x = np.array([rng.uniform(-60, 60), rng.uniform(-60, 60), rng.uniform(5, 40), rng.uniform(0, 360)])
+            u = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x, non_linear_process=geodetic_dynamics)
+            d, a, b = rng.choice([0.25, 1.0, 12.0]), rng.normal(0, 0.05), rng.normal(0, 0.5)
+            u.predict(dt=d, c=None, sog_rate=a, cog_rate=b)
+            px.append(x); pP.append(P); pdt.append(d); psr.append(a); pcr.append(b)
+            pxo.append(u.x[:, 0].copy()); pPo.append(u.P.copy())
+            zz = u.x[:, 0] + rng.normal(0, 0.3, 4); zz[3] += rng.choice([0, 360, -360, 180])
+            u.update(zz.copy())
+            uz.append(zz); uxo.append(u.x[:, 0].copy()); uPo.append(u.P.copy())
+    out.update(pr_x=np.array(px), pr_P=np.array(pP), pr_dt=np.array(pdt), pr_sr=np.array(psr), pr_cr=np.array(pcr),
+               pr_xo=np.array(pxo), pr_Po=np.array(pPo), up_z=np.array(uz), up_xo=np.array(uxo), up_Po=np.array(uPo),
+               H=H, Q=Q, R=R)
+    # robustification helpers, direct calls (unscented.py:389-511)
+    ci, lf, zs, Ps2, xs2 = [], [], [], [], []
+    for i in range(8):
+        A = rng.normal(size=(4, 4)) * 0.3; P = A @ A.T + np.eye(4) * 0.05
+        x = rng.normal(size=4)
+        u = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x)
+        zz = x + rng.normal(0, 3.0, 4)
+        c = u.criterion_index(zz.reshape(-1, 1), P, R)
+        l = u.update_lambda_factor(1.0, c, 50.0, zz.reshape(-1, 1), P, R)
+        ci.append(c); lf.append(l); zs.append(zz); Ps2.append(P); xs2.append(x)
+    out.update(rb_x=np.array(xs2), rb_P=np.array(Ps2), rb_z=np.array(zs), rb_ci=np.array(ci), rb_lambda=np.array(lf))
+    # generate_dts
+    out.update(gdts_in=np.array([10, 5, 3, 2, 1, 10, 10.0]), gdts_2=generate_dts([10, 5, 3, 2, 1, 10, 10], 2),
+               gdts_4=generate_dts([10, 5, 3, 2, 1, 10, 10], 4), gdts_3=generate_dts([23.0, 24.0, 25.0], 3))
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "ukf_synthetic.npz"), **pack_cases(synthetic_cases()))
+    np.savez_compressed(os.path.join(HERE, "ukf_edge.npz"), **pack_cases(edge_cases()))
+    np.savez_compressed(os.path.join(HERE, "ukf_ship_01203823.npz"), **pack_cases(real_case()))
+    np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+"""
+Parity of the HIP path (through the C ABI) with the golden vectors of the reference and with the oracle.
+Needs a real MI355X: run with ``pytest -m gpu``.
+
+Tolerances (BASELINE.json north_star / SURVEY.md §8d): state means <= 1e-6 relative element-wise
+(|d| / max(|ref|, 1e-12)); covariances max|dP| <= 1e-5 * max|P| per matrix.
+"""
+import types
+
+import numpy as np
+import pytest
+from conftest import load_cases
+
+pytestmark = pytest.mark.gpu
+
+MEAN_TOL = 1e-6
+COV_TOL = 1e-5
+
+CASES = [("ukf_synthetic.npz", i) for i in range(10)] + [("ukf_edge.npz", i) for i in range(3)] + [
+    ("ukf_ship_01203823.npz", i) for i in range(2)
+]
+
+
+def mean_err(a, ref):
+    return float(np.max(np.abs(a - ref) / np.maximum(np.abs(ref), 1e-12)))
+
+
+def cov_err(a, ref):
+    scale = np.max(np.abs(ref), axis=(-1, -2), keepdims=True)
+    return float(np.max(np.abs(a - ref) / scale))
+
+
+def _track(c):
+    return types.SimpleNamespace(z=c["z"], dts=c["dts"], sog_rate=c["sog_rate"], cog_rate=c["cog_rate"])
+
+
+def _noise(c):
+    if c["mode"] == "zero":
+        return None
+    return dict(noise_pred=c["noise_pred"], noise_upd=c["noise_upd"], noise_rts=c["noise_rts"])
+
+
+@pytest.mark.parametrize("name,i", CASES)
+def test_golden_single_track(name, i):
+    """Each reference-generated case as a batch of one, zero and replayed noise."""
+    from track_estimators import batch
+
+    c = load_cases(name)[i]
+    nz = _noise(c)
+    hb = batch.pack_tracks([_track(c)], [c["dt"]], [c["x0"]], c["H"], c["Q"], c["R"], c["P0"],
+                           noise=None if nz is None else [nz])
+    out = batch.run_batch(hb)
+    N = len(c["dt"])
+    assert mean_err(out["means"][0, : N + 1], c["means"]) < MEAN_TOL
+    assert cov_err(out["covs"][0, : N + 1], c["covs"]) < COV_TOL
+    assert mean_err(out["means_smoothed"][0, : N + 1], c["means_smoothed"]) < MEAN_TOL
+    assert cov_err(out["covs_smoothed"][0, : N + 1], c["covs_smoothed"]) < COV_TOL
+    expect_clamped = name == "ukf_edge.npz" and i == 2  # indefinite prior
+    assert bool(out["status"][0] & 0x2) == expect_clamped
+    assert not (out["status"][0] & 0x5)
+
+
+def test_golden_ragged_batch():
+    """All zero-noise golden cases with the example matrices in ONE ragged batch (different N and T per track),
+    replicated so that several waves and partially filled waves are exercised."""
+    from track_estimators import batch
+
+    cs = [c for c in load_cases("ukf_synthetic.npz") if c["mode"] == "zero"]
+    reps = 30
+    tracks = [_track(c) for c in cs] * reps
+    hb = batch.pack_tracks(tracks, [c["dt"] for c in cs] * reps, [c["x0"] for c in cs] * reps, cs[0]["H"], cs[0]["Q"],
+                           cs[0]["R"], cs[0]["P0"])
+    assert hb.B == len(cs) * reps and len(set(hb.nsteps.tolist())) > 1
+    out = batch.run_batch(hb)
+    for b in range(hb.B):
+        c = cs[b % len(cs)]
+        N = len(c["dt"])
+        assert mean_err(out["means"][b, : N + 1], c["means"]) < MEAN_TOL
+        assert cov_err(out["covs"][b, : N + 1], c["covs"]) < COV_TOL
+        assert mean_err(out["means_smoothed"][b, : N + 1], c["means_smoothed"]) < MEAN_TOL
+        assert cov_err(out["covs_smoothed"][b, : N + 1], c["covs_smoothed"]) < COV_TOL
+    # identical tracks in different batch positions give identical bits (no cross-track coupling)
+    for b in range(len(cs), hb.B):
+        N = hb.nsteps[b]
+        assert np.array_equal(out["means_smoothed"][b, : N + 1], out["means_smoothed"][b % len(cs), : N + 1])
+
+
+@pytest.mark.parametrize("B,nobs,s", [(1, 11, 2), (64, 26, 4), (65, 26, 4), (1000, 51, 2)])
+def test_synthetic_vs_oracle(B, nobs, s):
+    """Seeded synthetic batches vs the vectorised oracle, at sizes the oracle finishes in seconds."""
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(B, nobs=nobs, gap_h=1.0, seed0=1234)
+    hb = batch.pack_uniform(sb, s, H, Q, R, P0)
+    out = batch.run_batch(hb)
+    fires = hb.upd_idx.T >= 0
+    zidx = np.where(fires, hb.upd_idx.T, 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    m, P = orc.forward_batch(hb.x0.T, P0, H, Q, R, hb.dt.T, fires, zidx, ridx, sb.z, sb.sog_rate, sb.cog_rate)
+    rr = np.broadcast_to(batch.rts_rate_index(hb.Nmax + 1, nobs - 1, nobs), (B, hb.Nmax))
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T, rr, sb.sog_rate, sb.cog_rate)
+    assert not out["status"].any()
+    assert mean_err(out["means"], m) < MEAN_TOL
+    assert cov_err(out["covs"], P) < COV_TOL
+    assert mean_err(out["means_smoothed"], sm) < MEAN_TOL
+    assert cov_err(out["covs_smoothed"], sP) < COV_TOL
+
+
+def test_single_function_kernels():
+    """geodetic_dynamics and compute_sigma_points through the C ABI vs the reference's known answers."""
+    import ctypes as C
+    import os
+
+    import torch
+    from conftest import GOLDEN
+    from track_estimators._hip import binding
+
+    lib = binding.require_gpu()
+    k = np.load(os.path.join(GOLDEN, "kats.npz"))
+    dev = torch.device("cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = up(k["gd_x"].T)
+    dt, sr, cr = up(k["gd_dt"]), up(k["gd_sr"]), up(k["gd_cr"])
+    out = torch.empty_like(x)
+    binding.check(lib.ste_geodetic_dynamics_f64(64, x.data_ptr(), dt.data_ptr(), sr.data_ptr(), cr.data_ptr(),
+                                                out.data_ptr(), None), "geodetic")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy().T, k["gd_y"], rtol=1e-13, atol=1e-12)
+
+    n = len(k["sp_x"])
+    xs = up(k["sp_x"].T)
+    Ps = up(k["sp_P"].reshape(n, 16).T)
+    sig = torch.empty((9, 4, n), dtype=torch.float64, device=dev)
+    for scale, key in ((4.0 / (1 - (1 - 4 / 3.0)), "sp_sig_weighted"), (4.0, "sp_sig_unweighted")):
+        binding.check(lib.ste_sigma_points_f64(n, xs.data_ptr(), Ps.data_ptr(), C.c_double(scale), sig.data_ptr(), None),
+                      "sigma_points")
+        torch.cuda.synchronize()
+        got = sig.cpu().numpy().transpose(2, 1, 0)  # (n, 4, 9) like the reference's (n_state, n_sigma)
+        np.testing.assert_allclose(got, k[key], rtol=0, atol=1e-11)
