@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""
+bench.py — UKF + URTSS track-steps/s on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (forward UKF + unscented RTS smoother) over one batch of synthetic tracks that
+is already resident in HBM.  Workload at N=1: BASELINE.json configs[1] — 10 000 synthetic dim-4 geodetic tracks x 500
+steps, fp64 (126 observations at 1 h gaps, 4 sub-steps).  With N>1 (launched by torch.distributed.run,
+one rank per GPU over RCCL) every rank filters its own 10 000-track shard (weak scaling; tracks are independent) and
+the step ends with the one exchange the path has: an all-gather of the smoothed lon/lat (BASELINE.json configs[2]).
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      dominant kernel, algorithmic HBM bytes / HIP-event duration vs 8 TB/s (512 B per
+                track-step for the pair of kernels = 192 B forward + 320 B backward)
+  cpu_baseline  the NumPy oracle ("port" of the reference arithmetic) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.join(ROOT, "ship-track-estimators_amd")
+for p in (ROOT, PKG_ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+TRACKS_PER_GPU = 10_000
+NOBS = 126
+SUBSTEPS = 4
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6
+BYTES_FWD = 192  # per track-step: 32 B inputs + 160 B filtered mean/cov written
+BYTES_BWD = 320  # per track-step: 160 B filtered history re-read + 160 B smoothed written
+FLOPS_PER_TRACK_STEP = 2.0e4  # SURVEY.md §8d estimate (fp64 flop-equivalents, forward + backward)
+
+
+def cpu_baseline(ntracks: int):
+    """Time the oracle's vectorised restatement on `ntracks` tracks of the same workload (single process)."""
+    from track_estimators import batch, synthetic
+
+    from oracle import ukf_oracle as orc
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=0)
+    hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
+    fires = hb.upd_idx.T >= 0
+    zidx = np.where(fires, hb.upd_idx.T, 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    rr = np.broadcast_to(batch.rts_rate_index(hb.Nmax + 1, NOBS - 1, NOBS), (hb.B, hb.Nmax))
+    t0 = time.perf_counter()
+    m, P = orc.forward_batch(hb.x0.T, P0, H, Q, R, hb.dt.T, fires, zidx, ridx, sb.z, sb.sog_rate, sb.cog_rate)
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T, rr, sb.sog_rate, sb.cog_rate)
+    dt = time.perf_counter() - t0
+    return hb.track_steps / dt, dt, (m, P, sm, sP), hb
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="tracks per GPU")
+    ap.add_argument("--cpu-tracks", type=int, default=1024, help="tracks in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
+    args = ap.parse_args()
+
+    import torch
+
+    from track_estimators import batch, synthetic
+    from track_estimators._hip import binding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    lib = binding.require_gpu()
+    if args.lanes:
+        lib.ste_set_lanes_per_track(args.lanes)
+
+    # --- synthetic shard of this rank, resident in HBM before the timed region ---------------------------------
+    H, Q, R, P0 = synthetic.example_matrices()
+    B = args.tracks
+    sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=rank * B)
+    hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
+    db = batch.DeviceBatch(hb, device=dev)
+    gathered = None
+    if world > 1 and not args.no_gather:
+        gathered = torch.empty((world, hb.Nmax + 1, 2, B), dtype=torch.float64, device=dev)
+
+    stream = torch.cuda.current_stream(dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    def one_step(events=None):
+        if events is not None:
+            events[0].record(stream)
+        db.forward(stream)
+        if events is not None:
+            events[1].record(stream)
+        db.backward(stream)
+        if events is not None:
+            events[2].record(stream)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, db.sm_mean[:, :2, :].contiguous())
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    evs = [[ev(), ev(), ev()] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(evs[k])
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    status = db.status_host()
+    track_steps_rank = hb.track_steps
+    total_units = track_steps_rank * world * args.steps
+    value = total_units / elapsed
+
+    if rank == 0:
+        dom, dom_ms, dom_bytes = ("urtss_backward", bwd_ms, BYTES_BWD) if bwd_ms >= fwd_ms else (
+            "ukf_forward", fwd_ms, BYTES_FWD)
+        achieved = dom_bytes * track_steps_rank / (dom_ms * 1e-3) / 1e9
+        pair_gbs = (BYTES_FWD + BYTES_BWD) * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+        valu_tf = FLOPS_PER_TRACK_STEP * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+        out = {
+            "metric": "UKF+URTSS track-steps/sec (dim=4, 500-step tracks)",
+            "value": value,
+            "unit": "track-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{B} synthetic dim-4 geodetic tracks x {hb.Nmax} steps per GPU, UKF+URTSS, fp64 "
+                            "(BASELINE.json configs[1]); zero injected noise; inputs resident in HBM",
+                "tracks_per_gpu": B, "steps_per_track": int(hb.Nmax), "observations": NOBS, "substeps": SUBSTEPS,
+                "parallelism": f"track-sharded x{world}" + (", all-gather smoothed lon/lat" if gathered is not None else ""),
+                "lanes_per_track": int(lib.ste_set_lanes_per_track(args.lanes)),
+            },
+            "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},
+            "status_flagged_tracks": int((status != 0).sum()),
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "pair_achieved": pair_gbs,
+                "note": "path is fp64-VALU/latency bound, not HBM bound (SURVEY.md headline 6)",
+                "fp64_valu": {"achieved": valu_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tf / FP64_VALU_PEAK_TFLOPS, "flops_per_track_step": FLOPS_PER_TRACK_STEP},
+            },
+        }
+        if args.cpu_tracks > 0:
+            v, secs, ref, chb = cpu_baseline(args.cpu_tracks)
+            # the CPU sample is the first cpu_tracks tracks of rank 0's shard: cross-check the GPU result on it
+            n = min(args.cpu_tracks, B)
+            gm = db.sm_mean[:, :, :n].permute(2, 0, 1).cpu().numpy()
+            err = float(np.max(np.abs(gm - ref[2][:n]) / np.maximum(np.abs(ref[2][:n]), 1e-12)))
+            out["cpu_baseline"] = {
+                "value": v, "unit": "track-steps/s", "cores": 1, "kind": "port",
+                "sample": f"{args.cpu_tracks} tracks x {chb.Nmax} steps of the same synthetic workload "
+                          f"({secs:.1f} s, oracle/ukf_oracle.py vectorised NumPy, single process)",
+                "host_cpus": os.cpu_count(),
+                "gpu_vs_oracle_max_rel_err_smoothed_means": err,
+            }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

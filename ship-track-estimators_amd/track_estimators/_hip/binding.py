@@ -91,6 +91,11 @@ def load():
             f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "from the repo root (hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # PyTorch (device memory / streams / RCCL plumbing) bundles its own HIP runtime under the same soname as the
+    # system one.  Whichever is loaded first serves the whole process, and torch finds no GPU when the system copy won
+    # the race -- so make sure torch's copy is resident before libste_hip.so pulls in libamdhip64.so.7.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
