@@ -70,7 +70,7 @@ def main():
 
     import torch
 
-    from track_estimators import batch, synthetic
+    from track_estimators import batch, distributed, synthetic
     from track_estimators._hip import binding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,7 +114,7 @@ def main():
         if events is not None:
             events[2].record(stream)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, db.sm_mean[:, :2, :].contiguous())
+            distributed.gather_smoothed_positions(db.sm_mean, out=gathered)
 
     for _ in range(args.warmup):
         one_step()

@@ -10,6 +10,8 @@
  *   ste_urtss_backward_f64   KalmanFilterBase.run_rts_smoother kalman_filter.py:119-137
  *                            (+ UnscentedKalmanFilter.rts_step, unscented.py:267-351)
  *   ste_ukf_urtss_f64        both, back to back on one stream (examples/example_ukf_rts_smoother_batch.py:75-87)
+ *   ste_ukf_predict_f64      UnscentedKalmanFilter.predict (one step, many filters)   unscented.py:144-207
+ *   ste_ukf_update_f64       UnscentedKalmanFilter.update  (one step, many filters)   unscented.py:209-265
  *   ste_geodetic_dynamics_f64  geodetic_dynamics              kalman_filters/non_linear_process.py:6-85
  *   ste_sigma_points_f64     UnscentedKalmanFilter.compute_sigma_points  unscented.py:76-107
  *
@@ -129,10 +131,32 @@ int ste_geodetic_dynamics_f64(int64_t count, const double* x, const double* dt, 
                               const double* cog_rate, double* out, void* stream);
 
 /*
+ * One UKF predict on `count` independent (x, P) pairs.  x, x_out: [4][count]; P, P_out: [16][count];
+ * dt, sog_rate, cog_rate: [count]; noise: [4][count] or NULL; Q: HOST 4x4; status: [count] or NULL.
+ */
+int ste_ukf_predict_f64(int64_t count, const double* x, const double* P, const double* dt, const double* sog_rate,
+                        const double* cog_rate, const double* noise, const double* Q, double fan_scale, double w0,
+                        double wi, double* x_out, double* P_out, int32_t* status, void* stream);
+
+/*
+ * One linear-KF update (pinv gain, heading wrap, Joseph form) on `count` independent (x, P) pairs with observations
+ * z: [4][count]; noise: [4][count] or NULL (added to z); H, R: HOST 4x4.
+ */
+int ste_ukf_update_f64(int64_t count, const double* x, const double* P, const double* z, const double* noise,
+                       const double* H, const double* R, double* x_out, double* P_out, int32_t* status, void* stream);
+
+/*
  * Sigma fans of `count` (x, P) pairs: out[j][c][i] for sigma point j in 0..8, component c, pair i.
  * x: [4][count]; P: [16][count]; out: [9][4][count].  scale = n/(1-W0) (n when weights were never computed).
  */
 int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double scale, double* out, void* stream);
+
+/*
+ * Same for a general state dimension 1 <= n <= 16 (the reference's constructor and compute_sigma_points accept any n;
+ * its unit tests use n = 2).  x: [n][count]; P: [n*n][count]; out: [2n+1][n][count].  Not a hot path.
+ */
+int ste_sigma_points_generic_f64(int32_t n, int64_t count, const double* x, const double* P, double scale, double* out,
+                                 void* stream);
 
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.

@@ -19,11 +19,16 @@
 
 namespace ste {
 
+// Filter constants shared by every track: kernel arguments, so they sit in SGPRs / the scalar cache.
+struct Mats {
+    double fan_scale, w0, wi;
+    double H[16], Q[16], R[16];
+};
+
 struct KParams {
     int B, Nmax, Tmax;
     unsigned flags;
-    double fan_scale, w0, wi;
-    double H[16], Q[16], R[16];
+    Mats m;
     const int32_t* nsteps;
     const double* x0;
     const double* P0;
@@ -116,7 +121,7 @@ __device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const do
 }
 
 // UKF predict (unscented.py:178-207).  x, P updated in place.
-__device__ __forceinline__ int ukf_predict(const KParams& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
+__device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
                                            double cr, const double* noise, size_t nrow, size_t B, size_t t) {
     double sig[9][4];
     const int st = sigma_fan(x, P, p.fan_scale, sig);
@@ -153,7 +158,7 @@ __device__ __forceinline__ int ukf_predict(const KParams& p, double (&x)[4], dou
 }
 
 // Linear Kalman update with pseudo-inverse gain and Joseph-form covariance (unscented.py:219-265).
-__device__ __forceinline__ int ukf_update(const KParams& p, double (&x)[4], double (&P)[4][4], const double (&zin)[4],
+__device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double (&P)[4][4], const double (&zin)[4],
                                           const double* noise, size_t nrow, size_t B, size_t t) {
     double H[4][4], R[4][4];
     STE_UNROLL
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
     if (!(p.flags & STE_FLAG_NO_INITIAL_UPDATE)) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
-        st |= ukf_update(p, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+        st |= ukf_update(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
 
     // inputs of step 0
@@ -276,8 +281,8 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
                 cr_n = p.cog_rate[o];
                 ui_n = p.upd_idx[o];
             }
-            st |= ukf_predict(p, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t);
-            if (ui >= 0) st |= ukf_update(p, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            st |= ukf_predict(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t);
+            if (ui >= 0) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
             store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
         }
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 cr_n = crp[o];
             }
             double sig0[9][4], sig[9][4];
-            st |= sigma_fan(xk, Pk, p.fan_scale, sig0);
+            st |= sigma_fan(xk, Pk, p.m.fan_scale, sig0);
             STE_UNROLL
             for (int j = 0; j < 9; ++j) geodetic_step(sig0[j], dt, sr, cr, sig[j]);
             double xb[4];
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 double acc = 0.0;
                 STE_UNROLL
                 for (int j = 1; j < 9; ++j) acc += sig[j][c];
-                xb[c] = fma(p.w0, sig[0][c], p.wi * acc);
+                xb[c] = fma(p.m.w0, sig[0][c], p.m.wi * acc);
             }
             if (p.noise_rts) {
                 STE_UNROLL
@@ -363,13 +368,13 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 }
             }
             double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
-            weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
+            weighted_outer<true>(dk, dk, p.m.w0, p.m.wi, Pb);
             STE_UNROLL
             for (int r = 0; r < 4; ++r) {
                 STE_UNROLL
-                for (int c = 0; c < 4; ++c) Pb[r][c] += p.Q[r * 4 + c];
+                for (int c = 0; c < 4; ++c) Pb[r][c] += p.m.Q[r * 4 + c];
             }
-            weighted_outer<false>(sig0, db, p.w0, p.wi, D);  // unscented.py:328-330
+            weighted_outer<false>(sig0, db, p.m.w0, p.m.wi, D);  // unscented.py:328-330
             st |= sym_pinv4(Pb, Pbi);
             mm(D, Pbi, K);  // unscented.py:333
             double y[4];
@@ -436,6 +441,94 @@ __global__ __launch_bounds__(64) void sigma_points_kernel(size_t count, const do
     }
 }
 
+// Sigma fan for a general state dimension n <= kMaxGenericN (unscented.py:76-107 accepts any n; the reference's own
+// unit tests use n = 2).  Not a hot path: one lane per matrix, run-time loops, arrays in scratch.
+constexpr int kMaxGenericN = 16;
+__global__ __launch_bounds__(64) void sigma_points_generic_kernel(int n, size_t count, const double* x,
+                                                                  const double* P, double scale, double* out) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double A[kMaxGenericN][kMaxGenericN], V[kMaxGenericN][kMaxGenericN];
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            A[r][c] = scale * 0.5 * (P[((size_t)r * n + c) * count + i] + P[((size_t)c * n + r) * count + i]);
+            V[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+                if (!(apq * apq > kRotTol2 * fabs(app * aqq))) continue;
+                rotated = true;
+                const double delta = aqq - app;
+                double t = 2.0 * apq / (fabs(delta) + sqrt(delta * delta + 4.0 * apq * apq));
+                t = delta < 0.0 ? -t : t;
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int r = 0; r < n; ++r) {  // columns p, q
+                    const double arp = A[r][p], arq = A[r][q];
+                    A[r][p] = c * arp - s * arq;
+                    A[r][q] = s * arp + c * arq;
+                    const double vrp = V[r][p], vrq = V[r][q];
+                    V[r][p] = c * vrp - s * vrq;
+                    V[r][q] = s * vrp + c * vrq;
+                }
+                for (int r = 0; r < n; ++r) {  // rows p, q
+                    const double apr = A[p][r], aqr = A[q][r];
+                    A[p][r] = c * apr - s * aqr;
+                    A[q][r] = s * apr + c * aqr;
+                }
+                A[p][q] = 0.0;
+                A[q][p] = 0.0;
+            }
+        if (!rotated) break;
+    }
+    const size_t m = 2 * (size_t)n + 1;
+    for (int c = 0; c < n; ++c) out[((size_t)0 * n + c) * count + i] = x[(size_t)c * count + i];
+    for (int col = 0; col < n; ++col)
+        for (int r = 0; r < n; ++r) {
+            double t = 0.0;  // T[r][col] = sum_l V[r][l] sqrt(max(w_l,0)) V[col][l]
+            for (int l = 0; l < n; ++l) t += V[r][l] * sqrt(fmax(A[l][l], 0.0)) * V[col][l];
+            const double xr = x[(size_t)r * count + i];
+            out[((size_t)(1 + col) * n + r) * count + i] = xr + t;
+            out[((size_t)(1 + n + col) * n + r) * count + i] = xr - t;
+        }
+    (void)m;
+}
+
+// One predict (unscented.py:144-207) / one update (:209-265) on `count` independent (x, P) pairs.
+__global__ __launch_bounds__(64) void predict_kernel(size_t count, const Mats m, const double* x, const double* P,
+                                                     const double* dt, const double* sr, const double* cr,
+                                                     const double* noise, double* x_out, double* P_out,
+                                                     int32_t* status) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double xi[4], Pi[4][4];
+    load_vec(x, 0, count, i, xi);
+    load_mat(P, 0, count, i, Pi);
+    int st = ukf_predict(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i);
+    if (!all_finite(xi, Pi)) st |= STE_STATUS_NAN;
+    store_vec(x_out, 0, count, i, xi);
+    store_mat(P_out, 0, count, i, Pi);
+    if (status) status[i] = st;
+}
+
+__global__ __launch_bounds__(64) void update_kernel(size_t count, const Mats m, const double* x, const double* P,
+                                                    const double* z, const double* noise, double* x_out,
+                                                    double* P_out, int32_t* status) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double xi[4], Pi[4][4], zi[4];
+    load_vec(x, 0, count, i, xi);
+    load_mat(P, 0, count, i, Pi);
+    load_vec(z, 0, count, i, zi);
+    int st = ukf_update(m, xi, Pi, zi, noise, 0, count, i);
+    if (!all_finite(xi, Pi)) st |= STE_STATUS_NAN;
+    store_vec(x_out, 0, count, i, xi);
+    store_mat(P_out, 0, count, i, Pi);
+    if (status) status[i] = st;
+}
+
 }  // namespace ste
 
 // ===============================================================================================================
@@ -475,12 +568,12 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->Nmax = b->Nmax;
     kp->Tmax = b->Tmax;
     kp->flags = b->flags;
-    kp->fan_scale = b->fan_scale;
-    kp->w0 = b->w0;
-    kp->wi = b->wi;
-    memcpy(kp->H, b->H, sizeof(double) * 16);
-    memcpy(kp->Q, b->Q, sizeof(double) * 16);
-    memcpy(kp->R, b->R, sizeof(double) * 16);
+    kp->m.fan_scale = b->fan_scale;
+    kp->m.w0 = b->w0;
+    kp->m.wi = b->wi;
+    memcpy(kp->m.H, b->H, sizeof(double) * 16);
+    memcpy(kp->m.Q, b->Q, sizeof(double) * 16);
+    memcpy(kp->m.R, b->R, sizeof(double) * 16);
     kp->nsteps = b->nsteps;
     kp->x0 = b->x0;
     kp->P0 = b->P0;
@@ -568,6 +661,39 @@ int ste_geodetic_dynamics_f64(int64_t count, const double* x, const double* dt, 
     return check_hip(hipGetLastError(), "geodetic_dynamics launch");
 }
 
+int ste_ukf_predict_f64(int64_t count, const double* x, const double* P, const double* dt, const double* sog_rate,
+                        const double* cog_rate, const double* noise, const double* Q, double fan_scale, double w0,
+                        double wi, double* x_out, double* P_out, int32_t* status, void* stream) {
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !P || !dt || !sog_rate || !cog_rate || !Q || !x_out || !P_out) return fail(STE_EINVAL, "NULL pointer argument");
+    ste::Mats m;
+    memset(&m, 0, sizeof(m));
+    m.fan_scale = fan_scale;
+    m.w0 = w0;
+    m.wi = wi;
+    memcpy(m.Q, Q, sizeof(double) * 16);
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::predict_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, m, x, P, dt,
+                       sog_rate, cog_rate, noise, x_out, P_out, status);
+    return check_hip(hipGetLastError(), "ukf_predict launch");
+}
+
+int ste_ukf_update_f64(int64_t count, const double* x, const double* P, const double* z, const double* noise,
+                       const double* H, const double* R, double* x_out, double* P_out, int32_t* status, void* stream) {
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !P || !z || !H || !R || !x_out || !P_out) return fail(STE_EINVAL, "NULL pointer argument");
+    ste::Mats m;
+    memset(&m, 0, sizeof(m));
+    memcpy(m.H, H, sizeof(double) * 16);
+    memcpy(m.R, R, sizeof(double) * 16);
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, m, x, P, z,
+                       noise, x_out, P_out, status);
+    return check_hip(hipGetLastError(), "ukf_update launch");
+}
+
 int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double scale, double* out, void* stream) {
     if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
     if (count == 0) return STE_OK;
@@ -576,6 +702,18 @@ int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double
     hipLaunchKernelGGL(ste::sigma_points_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, x, P,
                        scale, out);
     return check_hip(hipGetLastError(), "sigma_points launch");
+}
+
+int ste_sigma_points_generic_f64(int32_t n, int64_t count, const double* x, const double* P, double scale, double* out,
+                                 void* stream) {
+    if (n < 1 || n > ste::kMaxGenericN) return fail(STE_EINVAL, "n must be in 1..16");
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !P || !out) return fail(STE_EINVAL, "NULL pointer argument");
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::sigma_points_generic_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (int)n,
+                       (size_t)count, x, P, scale, out);
+    return check_hip(hipGetLastError(), "sigma_points_generic launch");
 }
 
 }  // extern "C"

@@ -69,7 +69,11 @@ SYMBOLS = {
     "ste_urtss_backward_f64": (C.c_int, [C.POINTER(SteUkfBatchF64), C.c_void_p]),
     "ste_ukf_urtss_f64": (C.c_int, [C.POINTER(SteUkfBatchF64), C.c_void_p]),
     "ste_geodetic_dynamics_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
+    "ste_ukf_predict_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                      _dp, _dp, _dp, C.c_void_p]),
+    "ste_ukf_update_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_sigma_points_f64": (C.c_int, [C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
+    "ste_sigma_points_generic_f64": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
     "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
 }
 

@@ -1,0 +1,40 @@
+"""
+Track-sharded multi-GPU execution (one process per GPU, ``torch.distributed``; backend "nccl" is RCCL on ROCm).
+
+Tracks are independent (no cross-track term in kalman_filter.py:61-117 or unscented.py:285-351), so the batch is cut
+into contiguous blocks of tracks, one per rank, with no communication while filtering.  The only exchange is the final
+all-gather of the smoothed longitude/latitude histories (BASELINE.json configs[2]); the full means/covariances are 20x
+larger and stay on the rank that produced them.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_bounds(ntracks: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank ``rank``; the first ``ntracks % world`` ranks get one extra track."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    q, r = divmod(int(ntracks), int(world))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_smoothed_positions(sm_mean, group=None, out=None):
+    """
+    All-gather rows 0-1 (lon, lat) of a smoothed-mean tensor laid out [N+1][4][B_local] (include/ste.h).
+
+    Every rank must hold the same N and B_local (pad the last shard if the split is uneven).  Returns a tensor
+    [world][N+1][2][B_local] on every rank; rank r's block is ``out[r]``.  One collective, issued on the current stream
+    after the smoother kernel; with RCCL over xGMI each peer's shard travels on its own link.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    local = sm_mean[:, :2, :].contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    # concatenation along dim 0 is the layout both RCCL and gloo accept for all_gather_into_tensor
+    dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local, group=group)
+    return out

@@ -256,6 +256,17 @@ def real_case():
     return cases
 
 
+def csv_fixture():
+    """Rows of ship 01203823 cut from the reference's data file (the input of its own CLI example), plus one of the
+    header rows the source file repeats between ships, so the id column stays a string column as in the full file."""
+    import pandas as pd
+
+    df = pd.read_csv("/root/reference/data/historical_ships/historical_ship_data.csv", dtype=str, keep_default_na=False)
+    sub = df[df["primary.id"] == "01203823"]
+    hdr = pd.DataFrame([list(df.columns)], columns=df.columns)
+    pd.concat([sub, hdr], ignore_index=True).to_csv(os.path.join(HERE, "ship_01203823.csv"), index=False)
+
+
 def kats():
     """Per-function known answers."""
     rng = np.random.default_rng(7)
@@ -322,6 +333,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ukf_edge.npz"), **pack_cases(edge_cases()))
     np.savez_compressed(os.path.join(HERE, "ukf_ship_01203823.npz"), **pack_cases(real_case()))
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())
+    csv_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
