@@ -41,7 +41,7 @@ def geodetic_dynamics(x, c, dt, sog_rate=0.0, cog_rate=0.0):
     dev = torch.device("cuda", torch.cuda.current_device())
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
     xin = up(xs[:, :4].T)
-    bc = lambda v: up(np.broadcast_to(np.asarray(v, dtype=np.float64), (count,)))  # noqa: E731
+    bc = lambda v: up(np.array(np.broadcast_to(np.asarray(v, dtype=np.float64), (count,))))  # noqa: E731
     d, sr, cr = bc(dt), bc(sog_rate), bc(cog_rate)
     out = torch.empty_like(xin)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
