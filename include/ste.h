@@ -104,6 +104,16 @@ typedef struct ste_ukf_batch_f64 {
     double* sm_mean;  /* [Nmax+1][4][B]  smoothed; row nsteps = filtered row nsteps */
     double* sm_cov;   /* [Nmax+1][16][B] */
     int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
+
+    /*
+     * Optional workspace [Nmax][30][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts == cog_rate_rts ==
+     * NULL, ste_ukf_forward_f64 also evaluates the smoother's per-step back-prediction, P_b and gain K (which depend
+     * only on the filtered state of step k, unscented.py:297-333) while it has the sigma points in registers, stores them
+     * here, and ste_urtss_backward_f64 on the same batch runs only the sequential recurrence (unscented.py:337-349).
+     * Results are those of the stand-alone smoother to rounding.  NULL = the smoother recomputes everything from
+     * fwd_mean / fwd_cov (required when the forward history was not produced by ste_ukf_forward_f64 on this batch).
+     */
+    double* rts_work;
 } ste_ukf_batch_f64;
 
 int ste_version(void);

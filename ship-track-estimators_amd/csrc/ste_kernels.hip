@@ -47,7 +47,11 @@ struct KParams {
     double* sm_mean;
     double* sm_cov;
     int32_t* status;
+    double* rts_work;  // [Nmax][kWorkElems][B] smoother gains produced by the forward pass, or nullptr
 };
+
+// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | K row-major (16)
+constexpr int kWorkXb = 0, kWorkPb = 4, kWorkK = 14, kWorkElems = 30;
 
 __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
     STE_UNROLL
@@ -121,10 +125,26 @@ __device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const do
 }
 
 // UKF predict (unscented.py:178-207).  x, P updated in place.
+//
+// kGains: the smoother's step k (unscented.py:297-333) starts from the same filtered (x_k, P_k), builds the same sigma
+// fan and pushes it through the same process model with the same dt and rates, so its back-prediction x_b, its P_b
+// (centred on x_k, :324-325), its cross-covariance D (:328-330) and its gain K = D pinv(P_b) (:333) are functions of
+// values this predict already holds.  They are computed here, once, and written to rts_work; the backward pass is
+// then only the sequential recurrence (:337-349).  Valid when the smoother's rates equal the forward rates
+// (sog_rate_rts == NULL); otherwise the stand-alone backward kernel recomputes everything.
+template <bool kGains>
 __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
-                                           double cr, const double* noise, size_t nrow, size_t B, size_t t) {
-    double sig[9][4];
-    const int st = sigma_fan(x, P, p.fan_scale, sig);
+                                           double cr, const double* noise, size_t nrow, size_t B, size_t t,
+                                           const double* noise_rts = nullptr, double* work = nullptr) {
+    double sig[9][4], dev0[9][4];
+    int st = sigma_fan(x, P, p.fan_scale, sig);
+    if (kGains) {
+        STE_UNROLL
+        for (int j = 0; j < 9; ++j) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) dev0[j][c] = sig[j][c] - x[c];  // S_orig of unscented.py:329
+        }
+    }
     STE_UNROLL
     for (int j = 0; j < 9; ++j) {
         double o[4];
@@ -132,13 +152,57 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         STE_UNROLL
         for (int c = 0; c < 4; ++c) sig[j][c] = o[c];
     }
+    double m[4];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
         double acc = 0.0;
         STE_UNROLL
         for (int j = 1; j < 9; ++j) acc += sig[j][c];
-        x[c] = fma(p.w0, sig[0][c], p.wi * acc);
+        m[c] = fma(p.w0, sig[0][c], p.wi * acc);
     }
+    if (kGains && work) {
+        double xb[4], dk[9][4], db[9][4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) xb[c] = m[c];
+        if (noise_rts) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) xb[c] += noise_rts[(nrow * 4 + c) * B + t];
+        }
+        STE_UNROLL
+        for (int j = 0; j < 9; ++j) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                dk[j][c] = sig[j][c] - x[c];
+                db[j][c] = sig[j][c] - xb[c];
+            }
+        }
+        double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
+        weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Pb[r][c] += p.Q[r * 4 + c];
+        }
+        weighted_outer<false>(dev0, db, p.w0, p.wi, D);
+        st |= sym_pinv4(Pb, Pbi);
+        mm(D, Pbi, K);
+        double* w = work + (nrow * kWorkElems) * B + t;
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) w[(kWorkXb + c) * B] = xb[c];
+        int e = kWorkPb;
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = r; c < 4; ++c) w[(e++) * B] = Pb[r][c];
+        }
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = K[r][c];
+        }
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) x[c] = m[c];
     if (noise) {
         STE_UNROLL
         for (int c = 0; c < 4; ++c) x[c] += noise[(nrow * 4 + c) * B + t];
@@ -226,6 +290,7 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
 // ---------------------------------------------------------------------------------------------------------------
 // forward pass, one lane per track
 // ---------------------------------------------------------------------------------------------------------------
+template <bool kGains>
 __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -249,7 +314,22 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
     store_mat(p.fwd_cov, 0, B, t, P);
 
     int st = 0;
-    if (!(p.flags & STE_FLAG_NO_INITIAL_UPDATE)) {
+    const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
+    if (kGains && initial_update && ns > 0) {
+        // History row 0 is the PRIOR (kalman_filter.py:76-77) while the first predict starts from the state after the
+        // initial update, so the smoother's step 0 (which reads row 0, unscented.py:301) needs its own fan: run the
+        // predict arithmetic once on a copy of the prior, keep only the gains.
+        double xc[4], Pc[4][4];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            xc[r] = x[r];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Pc[r][c] = P[r][c];
+        }
+        st |= ukf_predict<true>(p.m, xc, Pc, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, 0, B, t, p.noise_rts,
+                                p.rts_work);
+    }
+    if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
         st |= ukf_update(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
@@ -281,7 +361,9 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
                 cr_n = p.cog_rate[o];
                 ui_n = p.upd_idx[o];
             }
-            st |= ukf_predict(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t);
+            // row 0's gains were taken from the prior above; every later row k is the state this predict starts from
+            double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
+            st |= ukf_predict<kGains>(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t, p.noise_rts, work);
             if (ui >= 0) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
             store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
@@ -411,6 +493,88 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// URTSS backward recurrence from gains precomputed by ukf_forward_l1<true> (unscented.py:337-349), one lane per track.
+// Per step it reads the filtered row (20 doubles) and the gain row (30 doubles) and writes the smoothed row (20): it is
+// HBM-latency/bandwidth bound, so the next step's 50 loads are issued before this step's arithmetic.
+// ---------------------------------------------------------------------------------------------------------------
+struct GainRow {
+    double xk[4], Pk[4][4], xb[4], Pb[4][4], K[4][4];
+};
+__device__ __forceinline__ void load_gain_row(const KParams& p, size_t k, size_t B, size_t t, GainRow& g) {
+    load_vec(p.fwd_mean, k, B, t, g.xk);
+    load_mat(p.fwd_cov, k, B, t, g.Pk);
+    const double* w = p.rts_work + (k * kWorkElems) * B + t;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) g.xb[c] = w[(kWorkXb + c) * B];
+    int e = kWorkPb;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            const double v = w[(e++) * B];
+            g.Pb[r][c] = v;
+            g.Pb[c][r] = v;
+        }
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) g.K[r][c] = w[(kWorkK + r * 4 + c) * B];
+    }
+}
+
+__global__ __launch_bounds__(64) void urtss_combine_l1(const KParams p) {
+    const size_t B = (size_t)p.B;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    double xs[4], Ps[4][4];
+    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
+    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+    GainRow nxt;
+    if (ns > 0) load_gain_row(p, (size_t)ns - 1, B, t, nxt);
+    for (int k = p.Nmax - 1; k >= 0; --k) {
+        if (!__any(k < ns)) continue;
+        if (k < ns) {
+            const GainRow g = nxt;
+            if (k > 0) load_gain_row(p, (size_t)k - 1, B, t, nxt);
+            double y[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) y[c] = xs[c] - g.xb[c];
+            y[3] = wrap180(y[3]);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                double acc = g.xk[r];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) acc = fma(g.K[r][c], y[c], acc);
+                xs[r] = acc;
+            }
+            xs[3] = floored_mod(xs[3], 360.0);
+            double dP[4][4], KdP[4][4], U[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) dP[r][c] = Ps[r][c] - g.Pb[r][c];
+            }
+            mm(g.K, dP, KdP);
+            mmt_sym(KdP, g.K, U);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) Ps[r][c] = g.Pk[r][c] + U[r][c];
+            }
+            store_vec(p.sm_mean, (size_t)k, B, t, xs);
+            store_mat(p.sm_cov, (size_t)k, B, t, Ps);
+        }
+    }
+    int st = 0;
+    if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
+    p.status[t] |= st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // single-function kernels (fine-grained API parity: geodetic_dynamics, compute_sigma_points)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void geodetic_kernel(size_t count, const double* x, const double* dt,
@@ -506,7 +670,7 @@ __global__ __launch_bounds__(64) void predict_kernel(size_t count, const Mats m,
     double xi[4], Pi[4][4];
     load_vec(x, 0, count, i, xi);
     load_mat(P, 0, count, i, Pi);
-    int st = ukf_predict(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i);
+    int st = ukf_predict<false>(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i);
     if (!all_finite(xi, Pi)) st |= STE_STATUS_NAN;
     store_vec(x_out, 0, count, i, xi);
     store_mat(P_out, 0, count, i, Pi);
@@ -592,18 +756,26 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_mean = b->sm_mean;
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
+    // gains can be shared between the passes only when both use the same rates (see ukf_predict<kGains>)
+    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts) ? nullptr : b->rts_work;
     return STE_OK;
 }
 
 int launch_forward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
-    hipLaunchKernelGGL(ste::ukf_forward_l1, dim3(grid), dim3(64), 0, s, kp);
+    if (kp.rts_work)
+        hipLaunchKernelGGL(ste::ukf_forward_l1<true>, dim3(grid), dim3(64), 0, s, kp);
+    else
+        hipLaunchKernelGGL(ste::ukf_forward_l1<false>, dim3(grid), dim3(64), 0, s, kp);
     return check_hip(hipGetLastError(), "ukf_forward launch");
 }
 
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
-    hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
+    if (kp.rts_work)
+        hipLaunchKernelGGL(ste::urtss_combine_l1, dim3(grid), dim3(64), 0, s, kp);
+    else
+        hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
     return check_hip(hipGetLastError(), "urtss_backward launch");
 }
 

@@ -57,6 +57,7 @@ class SteUkfBatchF64(C.Structure):
         ("sm_mean", _dp),
         ("sm_cov", _dp),
         ("status", _dp),
+        ("rts_work", _dp),
     ]
 
 

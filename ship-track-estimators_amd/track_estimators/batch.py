@@ -226,7 +226,7 @@ class DeviceBatch:
     _IN = ("nsteps", "x0", "P0", "dt", "sog_rate", "cog_rate", "sog_rate_rts", "cog_rate_rts", "upd_idx", "z",
            "noise_pred", "noise_upd", "noise_rts")
 
-    def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True):
+    def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True, fuse_gains: bool = True):
         import torch
 
         self.lib = binding.require_gpu()
@@ -244,6 +244,10 @@ class DeviceBatch:
         self.sm_mean = torch.empty((N + 1, 4, B), **f64) if alloc_smoothed else None
         self.sm_cov = torch.empty((N + 1, 16, B), **f64) if alloc_smoothed else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        # workspace for the smoother gains the forward pass can produce on the way (include/ste.h: rts_work)
+        self.rts_work = None
+        if alloc_smoothed and fuse_gains and hb.sog_rate_rts is None and hb.cog_rate_rts is None and N > 0:
+            self.rts_work = torch.empty((N, 30, B), **f64)
         fan_scale, w0, wi = sigma_constants(4, hb.weights_computed)
         self._keep = (hb.H, hb.Q, hb.R)
         s = binding.SteUkfBatchF64()
@@ -259,6 +263,7 @@ class DeviceBatch:
         s.sm_mean = None if self.sm_mean is None else self.sm_mean.data_ptr()
         s.sm_cov = None if self.sm_cov is None else self.sm_cov.data_ptr()
         s.status = self.status.data_ptr()
+        s.rts_work = None if self.rts_work is None else self.rts_work.data_ptr()
         self.struct = s
 
     def _stream(self, stream):
@@ -294,9 +299,9 @@ class DeviceBatch:
         return self.status.cpu().numpy()
 
 
-def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True):
+def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True):
     """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays."""
-    db = DeviceBatch(hb, device=device, alloc_smoothed=smooth)
+    db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains)
     if smooth:
         if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts).any():
             raise IndexError("smoother rate expansion too short for at least one track (unscented.py:287-292,310)")

@@ -40,16 +40,18 @@ def _noise(c):
     return dict(noise_pred=c["noise_pred"], noise_upd=c["noise_upd"], noise_rts=c["noise_rts"])
 
 
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused-gains", "standalone-smoother"])
 @pytest.mark.parametrize("name,i", CASES)
-def test_golden_single_track(name, i):
-    """Each reference-generated case as a batch of one, zero and replayed noise."""
+def test_golden_single_track(name, i, fuse):
+    """Each reference-generated case as a batch of one, zero and replayed noise; with the smoother gains produced by
+    the forward pass (rts_work) and with the stand-alone smoother kernel that recomputes them."""
     from track_estimators import batch
 
     c = load_cases(name)[i]
     nz = _noise(c)
     hb = batch.pack_tracks([_track(c)], [c["dt"]], [c["x0"]], c["H"], c["Q"], c["R"], c["P0"],
                            noise=None if nz is None else [nz])
-    out = batch.run_batch(hb)
+    out = batch.run_batch(hb, fuse_gains=fuse)
     N = len(c["dt"])
     assert mean_err(out["means"][0, : N + 1], c["means"]) < MEAN_TOL
     assert cov_err(out["covs"][0, : N + 1], c["covs"]) < COV_TOL
@@ -106,6 +108,21 @@ def test_synthetic_vs_oracle(B, nobs, s):
     assert cov_err(out["covs"], P) < COV_TOL
     assert mean_err(out["means_smoothed"], sm) < MEAN_TOL
     assert cov_err(out["covs_smoothed"], sP) < COV_TOL
+
+
+def test_fused_and_standalone_smoother_agree():
+    """The two smoother formulations are the same arithmetic in a different place: they agree far inside the parity
+    tolerance on a batch that fills several waves."""
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(300, nobs=41, gap_h=1.0, seed0=77)
+    hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    a = batch.run_batch(hb, fuse_gains=True)
+    b = batch.run_batch(hb, fuse_gains=False)
+    assert np.array_equal(a["means"], b["means"]) and np.array_equal(a["covs"], b["covs"])
+    assert mean_err(a["means_smoothed"], b["means_smoothed"]) < 1e-11
+    assert cov_err(a["covs_smoothed"], b["covs_smoothed"]) < 1e-11
 
 
 def test_single_function_kernels():
