@@ -50,7 +50,9 @@ struct KParams {
     double* rts_work;  // [Nmax][kWorkElems][B] smoother gains produced by the forward pass, or nullptr
 };
 
-// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | K row-major (16)
+constexpr int kColdEvery = 64;  // power of two
+
+// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | D, then K in place, row-major (16)
 constexpr int kWorkXb = 0, kWorkPb = 4, kWorkK = 14, kWorkElems = 30;
 
 __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
@@ -89,10 +91,22 @@ __device__ __forceinline__ bool all_finite(const double (&x)[4], const double (&
 
 // Sigma fan of (x, P): dev[i] = column i of sqrtm(scale*P) (unscented.py:95-105).  chi_{i+1} = x + dev[i],
 // chi_{i+1+n} = x - dev[i], chi_0 = x.  T is symmetric, so column i == row i.
+template <bool kWarm>
+__device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)[4][4], double scale,
+                                         double (&sig)[9][4], EigBasis& basis);
+
 __device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)[4][4], double scale,
                                          double (&sig)[9][4]) {
+    EigBasis none;
+    return sigma_fan<false>(x, P, scale, sig, none);
+}
+
+template <bool kWarm>
+__device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)[4][4], double scale,
+                                         double (&sig)[9][4], EigBasis& basis) {
     double T[4][4];
-    const int st = sym_sqrt4(P, scale, T);
+    const int st = sym_sqrt4<kWarm>(P, scale, T, basis);
+    if (kWarm) basis.valid = true;
     STE_UNROLL
     for (int c = 0; c < 4; ++c) sig[0][c] = x[c];
     STE_UNROLL
@@ -132,12 +146,13 @@ __device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const do
 // values this predict already holds.  They are computed here, once, and written to rts_work; the backward pass is
 // then only the sequential recurrence (:337-349).  Valid when the smoother's rates equal the forward rates
 // (sog_rate_rts == NULL); otherwise the stand-alone backward kernel recomputes everything.
-template <bool kGains>
+template <bool kGains, bool kWarm>
 __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
                                            double cr, const double* noise, size_t nrow, size_t B, size_t t,
-                                           const double* noise_rts = nullptr, double* work = nullptr) {
+                                           const double* noise_rts, double* work, EigBasis& fan_basis,
+                                           EigBasis& pb_basis) {
     double sig[9][4], dev0[9][4];
-    int st = sigma_fan(x, P, p.fan_scale, sig);
+    int st = sigma_fan<kWarm>(x, P, p.fan_scale, sig, fan_basis);
     if (kGains) {
         STE_UNROLL
         for (int j = 0; j < 9; ++j) {
@@ -176,7 +191,9 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
                 db[j][c] = sig[j][c] - xb[c];
             }
         }
-        double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
+        // The gain K = D pinv(P_b) is NOT on the forward recursion's critical path: P_b and D are stored and a fully
+        // parallel kernel (urtss_gain_kernel, one lane per (track, step)) turns D into K afterwards.
+        double Pb[4][4], D[4][4];
         weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
@@ -184,8 +201,7 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
             for (int c = 0; c < 4; ++c) Pb[r][c] += p.Q[r * 4 + c];
         }
         weighted_outer<false>(dev0, db, p.w0, p.wi, D);
-        st |= sym_pinv4(Pb, Pbi);
-        mm(D, Pbi, K);
+        (void)pb_basis;
         double* w = work + (nrow * kWorkElems) * B + t;
         STE_UNROLL
         for (int c = 0; c < 4; ++c) w[(kWorkXb + c) * B] = xb[c];
@@ -198,7 +214,7 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = K[r][c];
+            for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = D[r][c];
         }
     }
     STE_UNROLL
@@ -326,14 +342,22 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
             STE_UNROLL
             for (int c = 0; c < 4; ++c) Pc[r][c] = P[r][c];
         }
-        st |= ukf_predict<true>(p.m, xc, Pc, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, 0, B, t, p.noise_rts,
-                                p.rts_work);
+        EigBasis c0, c1;
+        st |= ukf_predict<true, false>(p.m, xc, Pc, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, 0, B, t,
+                                       p.noise_rts, p.rts_work, c0, c1);
     }
     if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
         st |= ukf_update(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
+
+    // Eigenvector bases of the two matrices decomposed every step (3P for the fan, P_b for the smoother gain): the
+    // next step's Jacobi solve starts from them.  Restarted from the identity every kColdEvery steps so rounding in
+    // the accumulated rotations cannot build up over a long track.
+    EigBasis fan_basis, pb_basis;
+    fan_basis.valid = false;
+    pb_basis.valid = false;
 
     // inputs of step 0
     double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
@@ -363,7 +387,12 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
             }
             // row 0's gains were taken from the prior above; every later row k is the state this predict starts from
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
-            st |= ukf_predict<kGains>(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t, p.noise_rts, work);
+            if ((k & (kColdEvery - 1)) == 0) {
+                fan_basis.valid = false;
+                pb_basis.valid = false;
+            }
+            st |= ukf_predict<kGains, true>(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t, p.noise_rts, work,
+                                            fan_basis, pb_basis);
             if (ui >= 0) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
             store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
@@ -403,6 +432,9 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
         cr_n = crp[o];
     }
     int st = 0;
+    EigBasis fan_basis, pb_basis;
+    fan_basis.valid = false;
+    pb_basis.valid = false;
     for (int k = p.Nmax - 1; k >= 0; --k) {
         if (!__any(k < ns)) continue;  // ragged batch: nobody in this wave has reached its last step yet
         if (k < ns) {
@@ -423,7 +455,11 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 cr_n = crp[o];
             }
             double sig0[9][4], sig[9][4];
-            st |= sigma_fan(xk, Pk, p.m.fan_scale, sig0);
+            if ((k & (kColdEvery - 1)) == kColdEvery - 1) {
+                fan_basis.valid = false;
+                pb_basis.valid = false;
+            }
+            st |= sigma_fan<true>(xk, Pk, p.m.fan_scale, sig0, fan_basis);
             STE_UNROLL
             for (int j = 0; j < 9; ++j) geodetic_step(sig0[j], dt, sr, cr, sig[j]);
             double xb[4];
@@ -457,7 +493,8 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 for (int c = 0; c < 4; ++c) Pb[r][c] += p.m.Q[r * 4 + c];
             }
             weighted_outer<false>(sig0, db, p.m.w0, p.m.wi, D);  // unscented.py:328-330
-            st |= sym_pinv4(Pb, Pbi);
+            st |= sym_pinv4<true>(Pb, Pbi, pb_basis);
+            pb_basis.valid = true;
             mm(D, Pbi, K);  // unscented.py:333
             double y[4];
             STE_UNROLL
@@ -497,6 +534,42 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
 // Per step it reads the filtered row (20 doubles) and the gain row (30 doubles) and writes the smoothed row (20): it is
 // HBM-latency/bandwidth bound, so the next step's 50 loads are issued before this step's arithmetic.
 // ---------------------------------------------------------------------------------------------------------------
+// K = D pinv(P_b) for every (track, step) at once (unscented.py:333).  Independent work items: the grid covers
+// Nmax*B lanes (track index fastest, so loads and stores stay coalesced) and fills every SIMD, unlike the sequential
+// passes.  Each lane: 26 loads, one 4x4 Jacobi eigen-solve, one 4x4 product, 16 stores.
+__global__ __launch_bounds__(256) void urtss_gain_kernel(const KParams p) {
+    const size_t B = (size_t)p.B;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)p.Nmax * B) return;
+    const size_t k = i / B, t = i - k * B;
+    if (p.nsteps && (int)k >= p.nsteps[t]) return;
+    double* w = p.rts_work + (k * kWorkElems) * B + t;
+    double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
+    int e = kWorkPb;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            const double v = w[(e++) * B];
+            Pb[r][c] = v;
+            Pb[c][r] = v;
+        }
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) D[r][c] = w[(kWorkK + r * 4 + c) * B];
+    }
+    const int st = sym_pinv4(Pb, Pbi);
+    mm(D, Pbi, K);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = K[r][c];
+    }
+    if (st) atomicOr(&p.status[t], st);
+}
+
 struct GainRow {
     double xk[4], Pk[4][4], xb[4], Pb[4][4], K[4][4];
 };
@@ -670,7 +743,8 @@ __global__ __launch_bounds__(64) void predict_kernel(size_t count, const Mats m,
     double xi[4], Pi[4][4];
     load_vec(x, 0, count, i, xi);
     load_mat(P, 0, count, i, Pi);
-    int st = ukf_predict<false>(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i);
+    EigBasis c0, c1;
+    int st = ukf_predict<false, false>(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i, nullptr, nullptr, c0, c1);
     if (!all_finite(xi, Pi)) st |= STE_STATUS_NAN;
     store_vec(x_out, 0, count, i, xi);
     store_mat(P_out, 0, count, i, Pi);
@@ -772,9 +846,15 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
 
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
-    if (kp.rts_work)
+    if (kp.rts_work) {
+        const size_t items = (size_t)kp.Nmax * (size_t)kp.B;
+        if (items) {
+            hipLaunchKernelGGL(ste::urtss_gain_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, kp);
+            int rc = check_hip(hipGetLastError(), "urtss_gain launch");
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(ste::urtss_combine_l1, dim3(grid), dim3(64), 0, s, kp);
-    else
+    } else
         hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
     return check_hip(hipGetLastError(), "urtss_backward launch");
 }

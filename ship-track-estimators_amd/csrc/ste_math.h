@@ -54,7 +54,18 @@ __device__ __forceinline__ void geodetic_step(const double (&x)[4], double dt, d
     out[3] = alpha * kRad2Deg + cog_rate * dt;
 }
 
+// 1/sqrt(x) for normal positive x: v_rsq_f64 (about 2^-24 relative) plus one third-order correction
+// y += y*e*(1/2 + 3/8 e), e = 1 - x*y^2, which leaves ~2^-70 before the final rounding.  No division, no v_sqrt.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
 // One Jacobi rotation on the (P,Q) plane of the symmetric A (both triangles kept), accumulating into V.
+// With delta = a_qq - a_pp and h = sqrt(delta^2 + 4 a_pq^2) the rotation that annihilates a_pq has
+//   cos^2 = (1 + |delta|/h)/2,   sin = +-a_pq / (h cos),   tan = sin / cos      (sign of tan = sign(delta) sign(a_pq))
+// which needs two reciprocal square roots and no division.
 template <int P, int Q>
 __device__ __forceinline__ bool jacobi_rot(double (&A)[4][4], double (&V)[4][4]) {
     const double apq = A[P][Q];
@@ -62,22 +73,23 @@ __device__ __forceinline__ bool jacobi_rot(double (&A)[4][4], double (&V)[4][4])
     const bool go = apq * apq > kRotTol2 * fabs(app * aqq);  // false for NaN and for apq == 0
     if (go) {
         const double delta = aqq - app;
-        const double hyp = sqrt(delta * delta + 4.0 * apq * apq);
-        double t = 2.0 * apq / (fabs(delta) + hyp);
-        t = delta < 0.0 ? -t : t;
-        const double c = 1.0 / sqrt(1.0 + t * t);
-        const double s = t * c;
-        const double tau = s / (1.0 + c);
-        A[P][P] = app - t * apq;
-        A[Q][Q] = aqq + t * apq;
+        const double two_apq = apq + apq;
+        const double rh = rsqrt_fast(fma(delta, delta, two_apq * two_apq));
+        const double c2 = fma(0.5 * fabs(delta), rh, 0.5);  // in [1/2, 1]
+        const double rc = rsqrt_fast(c2);                   // 1 / cos
+        const double c = c2 * rc;
+        const double s = (delta < 0.0 ? -apq : apq) * rh * rc;
+        const double t = s * rc;
+        A[P][P] = fma(-t, apq, app);
+        A[Q][Q] = fma(t, apq, aqq);
         A[P][Q] = 0.0;
         A[Q][P] = 0.0;
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             if (r != P && r != Q) {
                 const double arp = A[r][P], arq = A[r][Q];
-                const double np_ = arp - s * (arq + tau * arp);
-                const double nq_ = arq + s * (arp - tau * arq);
+                const double np_ = fma(c, arp, -(s * arq));
+                const double nq_ = fma(s, arp, c * arq);
                 A[r][P] = np_;
                 A[P][r] = np_;
                 A[r][Q] = nq_;
@@ -87,36 +99,76 @@ __device__ __forceinline__ bool jacobi_rot(double (&A)[4][4], double (&V)[4][4])
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             const double vrp = V[r][P], vrq = V[r][Q];
-            V[r][P] = vrp - s * (vrq + tau * vrp);
-            V[r][Q] = vrq + s * (vrp - tau * vrq);
+            V[r][P] = fma(c, vrp, -(s * vrq));
+            V[r][Q] = fma(s, vrp, c * vrq);
         }
     }
     return go;
 }
 
-// Cyclic Jacobi eigen-decomposition of a symmetric 4x4: A = V diag(w) V^T.  A is destroyed.
+// Cyclic Jacobi sweeps on the symmetric A, accumulating rotations into V (which the caller initialised).
 // Returns false if the sweep cap was hit.  The wave leaves the loop together (__any), but each lane's rotations are
 // gated by its own data only, so a track's result does not depend on which tracks share its wave.
-__device__ __forceinline__ bool jacobi_eig4(double (&A)[4][4], double (&V)[4][4], double (&w)[4]) {
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
-    }
+__device__ __forceinline__ bool jacobi_sweeps(double (&A)[4][4], double (&V)[4][4], double (&w)[4]) {
     bool rotated = true;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
         rotated = jacobi_rot<0, 1>(A, V);
+        rotated |= jacobi_rot<2, 3>(A, V);
         rotated |= jacobi_rot<0, 2>(A, V);
+        rotated |= jacobi_rot<1, 3>(A, V);
         rotated |= jacobi_rot<0, 3>(A, V);
         rotated |= jacobi_rot<1, 2>(A, V);
-        rotated |= jacobi_rot<1, 3>(A, V);
-        rotated |= jacobi_rot<2, 3>(A, V);
         if (!__any(rotated)) break;
     }
     STE_UNROLL
     for (int i = 0; i < 4; ++i) w[i] = A[i][i];
     return !rotated;
 }
+
+// Cold start: A = V diag(w) V^T from V = I.  A is destroyed.
+__device__ __forceinline__ bool jacobi_eig4(double (&A)[4][4], double (&V)[4][4], double (&w)[4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+    return jacobi_sweeps(A, V, w);
+}
+
+// Warm start: V holds the eigenvectors of a nearby matrix (the same quantity one filter step earlier).  A is first
+// moved into that basis, B = V^T A V, which is nearly diagonal, so one or two sweeps finish the job; the rotations keep
+// accumulating into V.  Same fixed point as the cold start, to rounding.
+__device__ __forceinline__ bool jacobi_eig4_warm(double (&A)[4][4], double (&V)[4][4], double (&w)[4]) {
+    double M[4][4], Bm[4][4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            double acc = A[r][0] * V[0][c];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(A[r][i], V[i][c], acc);
+            M[r][c] = acc;
+        }
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) {
+            double acc = V[0][r] * M[0][c];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(V[i][r], M[i][c], acc);
+            Bm[r][c] = acc;
+            Bm[c][r] = acc;
+        }
+    }
+    return jacobi_sweeps(Bm, V, w);
+}
+
+// Eigenvector basis carried from one filter step to the next for one recurring symmetric matrix.
+struct EigBasis {
+    double V[4][4];
+    bool valid;
+};
 
 // out = V diag(f) V^T (symmetric, upper triangle computed and mirrored).
 __device__ __forceinline__ void recompose(const double (&V)[4][4], const double (&f)[4], double (&out)[4][4]) {
@@ -141,8 +193,10 @@ __device__ __forceinline__ void recompose(const double (&V)[4][4], const double 
 
 // Principal square root of (scale * P) with negative eigenvalues clamped: the real part of scipy.linalg.sqrtm on a
 // symmetric matrix (unscented.py:95-97).  P is symmetrised first.  Returns status bits.
-__device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, double (&T)[4][4]) {
-    double A[4][4], V[4][4], w[4], f[4];
+template <bool kWarm>
+__device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, double (&T)[4][4], EigBasis& basis) {
+    double A[4][4], w[4], f[4];
+    double (&V)[4][4] = basis.V;
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
@@ -156,7 +210,13 @@ __device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, 
     double wmax = 0.0;
     STE_UNROLL
     for (int i = 0; i < 4; ++i) wmax = fmax(wmax, fabs(A[i][i]));
-    if (!jacobi_eig4(A, V, w)) st |= 0x4;
+    bool ok;
+    if (kWarm && basis.valid) {
+        ok = jacobi_eig4_warm(A, V, w);
+    } else {
+        ok = jacobi_eig4(A, V, w);
+    }
+    if (!ok) st |= 0x4;
     STE_UNROLL
     for (int i = 0; i < 4; ++i) {
         if (w[i] < -1e-12 * wmax) st |= 0x2;
@@ -168,8 +228,10 @@ __device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, 
 
 // Moore–Penrose pseudo-inverse of a symmetric 4x4 with NumPy's cutoff: singular values (= |eigenvalues|) not larger
 // than rcond * max are dropped (np.linalg.pinv as called at unscented.py:243 and :333).
-__device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4][4]) {
-    double A[4][4], V[4][4], w[4], f[4];
+template <bool kWarm>
+__device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4][4], EigBasis& basis) {
+    double A[4][4], w[4], f[4];
+    double (&V)[4][4] = basis.V;
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
@@ -180,7 +242,13 @@ __device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4
         }
     }
     int st = 0;
-    if (!jacobi_eig4(A, V, w)) st |= 0x4;
+    bool ok;
+    if (kWarm && basis.valid) {
+        ok = jacobi_eig4_warm(A, V, w);
+    } else {
+        ok = jacobi_eig4(A, V, w);
+    }
+    if (!ok) st |= 0x4;
     double smax = 0.0;
     STE_UNROLL
     for (int i = 0; i < 4; ++i) smax = fmax(smax, fabs(w[i]));
@@ -189,6 +257,11 @@ __device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4
     for (int i = 0; i < 4; ++i) f[i] = (fabs(w[i]) > cutoff) ? 1.0 / w[i] : 0.0;
     recompose(V, f, Si);
     return st;
+}
+
+__device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4][4]) {
+    EigBasis none;
+    return sym_pinv4<false>(S, Si, none);
 }
 
 // C = A * B (4x4)

@@ -11,7 +11,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))  # .../ship-track-estimators_amd
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libste_hip.so")
+# STE_LIB_PATH: developer override to A/B an experimental build of the same ABI
+LIB_PATH = os.environ.get("STE_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libste_hip.so")
 
 STE_FLAG_SHARED_P0 = 0x1
 STE_FLAG_NO_INITIAL_UPDATE = 0x2
