@@ -120,6 +120,61 @@ __device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)
     return st;
 }
 
+// Sigma fan of (x, P) pushed through the process model (unscented.py:183-191 = :301-312):
+//   sig0[j]  the fan itself: x, x + col_i(T), x - col_i(T) with T = sqrtm(scale * P)
+//   sig[j]   geodetic_dynamics(sig0[j], dt, sog_rate, cog_rate)
+// The 2n points come in +- pairs around the centre, so their angles are (centre angle) +- (small increment) and
+// sin/cos of all of them follow from the centre's three sincos and one sincos per increment by the angle-addition
+// formulas: 15 sincos evaluations instead of 27, 12 of them on small arguments that need no range reduction.
+template <bool kWarm>
+__device__ __forceinline__ int propagate_fan(const double (&x)[4], const double (&P)[4][4], double scale, double dt,
+                                             double sr, double cr, double (&sig0)[9][4], double (&sig)[9][4],
+                                             EigBasis& basis) {
+    double T[4][4];
+    const int st = sym_sqrt4<kWarm>(P, scale, T, basis);
+    if (kWarm) basis.valid = true;
+    const double dt_r = dt / kEarthRadius;
+    const double du = sr * dt, da = cr * dt;
+    // centre
+    const double lat0 = x[1] * kDeg2Rad, alpha0 = x[3] * kDeg2Rad, delta0 = x[2] * dt_r;
+    double sp0, cp0, sa0, ca0, sd0, cd0;
+    sincos_fast(lat0, sp0, cp0);
+    sincos_fast(alpha0, sa0, ca0);
+    sincos_fast(delta0, sd0, cd0);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) sig0[0][c] = x[c];
+    geodetic_finish(x[0] * kDeg2Rad, lat0, sp0, cp0, sa0, ca0, sd0, cd0, sig[0][0], sig[0][1]);
+    sig[0][2] = x[2] + du;
+    sig[0][3] = alpha0 * kRad2Deg + da;
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        // increments of the three angles along column i of T (T symmetric: T[c][i] == T[i][c])
+        double sdp, cdp, sda, cda, sdd, cdd;
+        sincos_delta(T[1][i] * kDeg2Rad, sdp, cdp);
+        sincos_delta(T[3][i] * kDeg2Rad, sda, cda);
+        sincos_delta(T[2][i] * dt_r, sdd, cdd);
+        const double p1 = sp0 * cdp, p2 = cp0 * sdp, p3 = cp0 * cdp, p4 = sp0 * sdp;
+        const double a1 = sa0 * cda, a2 = ca0 * sda, a3 = ca0 * cda, a4 = sa0 * sda;
+        const double d1 = sd0 * cdd, d2 = cd0 * sdd, d3 = cd0 * cdd, d4 = sd0 * sdd;
+        STE_UNROLL
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const int j = 1 + i + 4 * sgn;
+            double pt[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) pt[c] = sgn ? x[c] - T[c][i] : x[c] + T[c][i];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) sig0[j][c] = pt[c];
+            const double sp = sgn ? p1 - p2 : p1 + p2, cp = sgn ? p3 + p4 : p3 - p4;
+            const double sa = sgn ? a1 - a2 : a1 + a2, ca = sgn ? a3 + a4 : a3 - a4;
+            const double sd = sgn ? d1 - d2 : d1 + d2, cd = sgn ? d3 + d4 : d3 - d4;
+            geodetic_finish(pt[0] * kDeg2Rad, pt[1] * kDeg2Rad, sp, cp, sa, ca, sd, cd, sig[j][0], sig[j][1]);
+            sig[j][2] = pt[2] + du;
+            sig[j][3] = (pt[3] * kDeg2Rad) * kRad2Deg + da;
+        }
+    }
+    return st;
+}
+
 // sum_j W_j a_j b_j^T  for two sets of 9 deviation vectors.
 template <bool kSym>
 __device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const double (&b)[9][4], double w0, double wi,
@@ -152,20 +207,13 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
                                            const double* noise_rts, double* work, EigBasis& fan_basis,
                                            EigBasis& pb_basis) {
     double sig[9][4], dev0[9][4];
-    int st = sigma_fan<kWarm>(x, P, p.fan_scale, sig, fan_basis);
+    int st = propagate_fan<kWarm>(x, P, p.fan_scale, dt, sr, cr, dev0, sig, fan_basis);
     if (kGains) {
         STE_UNROLL
         for (int j = 0; j < 9; ++j) {
             STE_UNROLL
-            for (int c = 0; c < 4; ++c) dev0[j][c] = sig[j][c] - x[c];  // S_orig of unscented.py:329
+            for (int c = 0; c < 4; ++c) dev0[j][c] -= x[c];  // S_orig of unscented.py:329
         }
-    }
-    STE_UNROLL
-    for (int j = 0; j < 9; ++j) {
-        double o[4];
-        geodetic_step(sig[j], dt, sr, cr, o);
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) sig[j][c] = o[c];
     }
     double m[4];
     STE_UNROLL
@@ -459,9 +507,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 fan_basis.valid = false;
                 pb_basis.valid = false;
             }
-            st |= sigma_fan<true>(xk, Pk, p.m.fan_scale, sig0, fan_basis);
-            STE_UNROLL
-            for (int j = 0; j < 9; ++j) geodetic_step(sig0[j], dt, sr, cr, sig[j]);
+            st |= propagate_fan<true>(xk, Pk, p.m.fan_scale, dt, sr, cr, sig0, sig, fan_basis);
             double xb[4];
             STE_UNROLL
             for (int c = 0; c < 4; ++c) {

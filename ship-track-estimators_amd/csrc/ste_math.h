@@ -34,6 +34,138 @@ __device__ __forceinline__ double floored_mod(double a, double b) {
 // (y + 180) % 360 - 180   (unscented.py:250, :340)
 __device__ __forceinline__ double wrap180(double y) { return floored_mod(y + 180.0, 360.0) - 180.0; }
 
+// 1/sqrt(x) for normal positive x: v_rsq_f64 (about 2^-24 relative) plus one third-order correction
+// y += y*e*(1/2 + 3/8 e), e = 1 - x*y^2, which leaves ~2^-70 before the final rounding.  No division, no v_sqrt.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Transcendentals.  The device library's sincos/atan2/asin cost 40/34/14-42 fp64-FMA issue slots each (measured on
+// gfx950, one wave per SIMD) and the fan needs 27/9/9 of them per step, so the common cases are inlined here with
+// fdlibm's kernels (same minimax polynomials, < 1 ulp on their intervals) and everything unusual drops to the library.
+// ---------------------------------------------------------------------------------------------------------------
+
+// sin and cos on |r| <= pi/4 (fdlibm __kernel_sin / __kernel_cos polynomials).
+__device__ __forceinline__ void sincos_kernel(double r, double& s, double& c) {
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    s = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    c = fma(z * z, pc, fma(-0.5, z, 1.0));
+}
+
+// sincos for |x| < 2^20 by two-constant Cody–Waite reduction with FMA (n*pi/2 is removed exactly in the first FMA,
+// the second restores the bits of pi/2 beyond double precision); larger arguments use the library's Payne–Hanek path.
+__device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
+    if (__builtin_expect(!(fabs(x) < 1048576.0), 0)) {
+        sincos(x, &s, &c);
+        return;
+    }
+    const double n = rint(x * 0.63661977236758134308);  // 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    double sk, ck;
+    sincos_kernel(r, sk, ck);
+    const int q = (int)n;
+    const double sv = (q & 1) ? ck : sk;
+    const double cv = (q & 1) ? sk : ck;
+    s = (q & 2) ? -sv : sv;
+    c = ((q + 1) & 2) ? -cv : cv;
+}
+
+// atan on |q| <= 7/16 (fdlibm atan's polynomial for its first interval).
+__device__ __forceinline__ double atan_small(double q) {
+    const double z = q * q, w = z * z;
+    double s1 = fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    s1 = fma(w, s1, 6.66107313738753120669e-02);
+    s1 = fma(w, s1, 9.09088713343650656196e-02);
+    s1 = fma(w, s1, 1.42857142725034663711e-01);
+    s1 = fma(w, s1, 3.33333333333329318027e-01);
+    double s2 = fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    s2 = fma(w, s2, -7.69187620504482999495e-02);
+    s2 = fma(w, s2, -1.11111104054623557880e-01);
+    s2 = fma(w, s2, -1.99999999998764832476e-01);
+    return fma(-q, fma(z, s1, w * s2), q);
+}
+
+// a / b for normal b > 0: v_rcp_f64 (~2^-24) refined twice, then one residual correction of the quotient.
+__device__ __forceinline__ double div_pos(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// atan2(a, b): a ship moves a small angle per step, so b (= cos(lat') cos(dlon)) is positive and |a| << b almost always.
+__device__ __forceinline__ double atan2_fast(double a, double b) {
+    if (__builtin_expect(b > 1e-300 && fabs(a) <= 0.4375 * b, 1)) return atan_small(div_pos(a, b));
+    return atan2(a, b);
+}
+
+// asin on |x| <= 1/2 (fdlibm asin's rational approximation for that interval).
+__device__ __forceinline__ double asin_small(double x) {
+    const double t = x * x;
+    double pn = fma(t, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    pn = fma(t, pn, -4.00555345006794114027e-02);
+    pn = fma(t, pn, 2.01212532134862925881e-01);
+    pn = fma(t, pn, -3.25565818622400915405e-01);
+    pn = fma(t, pn, 1.66666666666666657415e-01);
+    pn *= t;
+    double qd = fma(t, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    qd = fma(t, qd, 2.02094576023350569471e+00);
+    qd = fma(t, qd, -2.40339491173441421878e+00);
+    qd = fma(t, qd, 1.0);
+    return fma(x, div_pos(pn, qd), x);
+}
+
+// The part of the great-circle step after the three sin/cos pairs are known (non_linear_process.py:64-72).
+// (lon_r, lat_r) are the point's longitude/latitude in radians; returns lon', lat' in degrees.
+//
+// Latitude: the reference takes asin(sin(lat')).  Here lat' = lat + asin(sin(lat' - lat)) with
+// sin(lat' - lat) = sin(lat') cos(lat) - cos(lat') sin(lat) and cos(lat') = hypot(a, b) (a = cos(lat') sin(dlon),
+// b = cos(lat') cos(dlon) are the atan2 operands).  The argument is then of the size of the step, inside asin's
+// polynomial interval, and the result keeps its accuracy near the poles.  Steps over 30 degrees use asin(sin(lat')).
+__device__ __forceinline__ void geodetic_finish(double lon_r, double lat_r, double sp, double cp, double sa, double ca,
+                                                double sd, double cd, double& lon_out, double& lat_out) {
+    const double a = sd * sa;
+    const double sdca = sd * ca;
+    const double b = fma(cp, cd, -(sp * sdca));
+    const double sl = fma(sp, cd, cp * sdca);  // sin(lat')
+    lon_out = (lon_r + atan2_fast(a, b)) * kRad2Deg;
+    const double h2 = fma(a, a, b * b);
+    const double cl = h2 * rsqrt_fast(h2);  // cos(lat') >= 0
+    const double xs = fma(sl, cp, -(cl * sp));
+    double lat2;
+    if (__builtin_expect(fabs(xs) <= 0.5 && h2 > 1e-300, 1)) {
+        lat2 = lat_r + asin_small(xs);
+    } else {
+        lat2 = asin(sl);
+    }
+    lat_out = lat2 * kRad2Deg;
+}
+
+// sincos of a small increment: the kernels directly when |d| <= pi/4 (always, for a sigma-point deviation of a tracked
+// ship), the reducing version otherwise.
+__device__ __forceinline__ void sincos_delta(double d, double& s, double& c) {
+    if (__builtin_expect(fabs(d) <= 0.78539816339744828, 1)) {
+        sincos_kernel(d, s, c);
+    } else {
+        sincos_fast(d, s, c);
+    }
+}
+
 // Great-circle dead reckoning of one state (non_linear_process.py:46-85, c = None).
 __device__ __forceinline__ void geodetic_step(const double (&x)[4], double dt, double sog_rate, double cog_rate,
                                               double (&out)[4]) {
@@ -43,23 +175,12 @@ __device__ __forceinline__ void geodetic_step(const double (&x)[4], double dt, d
     const double alpha = x[3] * kDeg2Rad;
     const double udt_r = u * dt / kEarthRadius;
     double sd, cd, sa, ca, sp, cp;
-    sincos(udt_r, &sd, &cd);
-    sincos(alpha, &sa, &ca);
-    sincos(lat, &sp, &cp);
-    const double term_a = sd * sa;
-    const double term_b = cp * cd - sp * sd * ca;
-    out[0] = (lon + atan2(term_a, term_b)) * kRad2Deg;
-    out[1] = asin(sp * cd + cp * sd * ca) * kRad2Deg;
+    sincos_fast(udt_r, sd, cd);
+    sincos_fast(alpha, sa, ca);
+    sincos_fast(lat, sp, cp);
+    geodetic_finish(lon, lat, sp, cp, sa, ca, sd, cd, out[0], out[1]);
     out[2] = u + sog_rate * dt;
     out[3] = alpha * kRad2Deg + cog_rate * dt;
-}
-
-// 1/sqrt(x) for normal positive x: v_rsq_f64 (about 2^-24 relative) plus one third-order correction
-// y += y*e*(1/2 + 3/8 e), e = 1 - x*y^2, which leaves ~2^-70 before the final rounding.  No division, no v_sqrt.
-__device__ __forceinline__ double rsqrt_fast(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-(x * y), y, 1.0);
-    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 // One Jacobi rotation on the (P,Q) plane of the symmetric A (both triangles kept), accumulating into V.
