@@ -32,8 +32,12 @@ NOBS = 126
 SUBSTEPS = 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6
-BYTES_FWD = 192  # per track-step: 32 B inputs + 160 B filtered mean/cov written
-BYTES_BWD = 320  # per track-step: 160 B filtered history re-read + 160 B smoothed written
+BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mean/cov written
+BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
+# Measured HBM bytes per track-step (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.csv).
+# Above the algorithmic figure by the rts_work rows the forward pass hands to the smoother.
+TRAFFIC_FWD = 438
+TRAFFIC_BWD = 337 + 560  # urtss_gain_kernel + urtss_combine_l1
 FLOPS_PER_TRACK_STEP = 2.0e4  # SURVEY.md §8d estimate (fp64 flop-equivalents, forward + backward)
 
 
@@ -144,8 +148,8 @@ def main():
     value = total_units / elapsed
 
     if rank == 0:
-        dom, dom_ms, dom_bytes = ("urtss_backward", bwd_ms, BYTES_BWD) if bwd_ms >= fwd_ms else (
-            "ukf_forward", fwd_ms, BYTES_FWD)
+        dom, dom_ms, dom_bytes, dom_traffic = ("urtss_backward", bwd_ms, BYTES_BWD, TRAFFIC_BWD) if bwd_ms >= fwd_ms else (
+            "ukf_forward", fwd_ms, BYTES_FWD, TRAFFIC_FWD)
         achieved = dom_bytes * track_steps_rank / (dom_ms * 1e-3) / 1e9
         pair_gbs = (BYTES_FWD + BYTES_BWD) * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
         valu_tf = FLOPS_PER_TRACK_STEP * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
@@ -173,7 +177,12 @@ def main():
             "status_flagged_tracks": int((status != 0).sum()),
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": dom_traffic * track_steps_rank if (args.lanes in (0, 1) and db.rts_work is not None) else None,
+                "traffic_unit": "bytes per launch",
+                "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                  "passes of this command; FETCH_SIZE doubled per the gfx950 calibration in profiles/README.md)",
+                "algorithmic_bytes_per_track_step": dom_bytes,
                 "pair_achieved": pair_gbs,
                 "note": "path is fp64-VALU/latency bound, not HBM bound (SURVEY.md headline 6)",
                 "fp64_valu": {"achieved": valu_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
