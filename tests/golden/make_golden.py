@@ -256,6 +256,52 @@ def real_case():
     return cases
 
 
+def gp_cases():
+    """GP path: the reference's GPRegression (a wrapper over scikit-learn) on ship 01203823 and on synthetic tracks.
+    Per case: log-marginal likelihood + gradient at fixed thetas, predict mean/std at fixed theta (optimizer=None),
+    and one seeded full fit (n_restarts_optimizer=3, random_state=0)."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from track_estimators.gaussian_processes.gaussian_process import GPRegression
+
+    out = {}
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv(csv_file="/root/reference/data/historical_ships/historical_ship_data.csv", ship_id="01203823",
+                id_col="primary.id", lat_col="lat", lon_col="lon")
+    tracks = [("ship", st)]
+    for name, nobs in (("syn130", 130), ("syn300", 300)):
+        sb = synthetic.make_batch(1, nobs=nobs, gap_h=1.0, seed0=500 + nobs)
+        t = ShipTrack()
+        t.lon, t.lat, t.dts = sb.lon[0], sb.lat[0], sb.dts[0] * np.random.default_rng(nobs).choice([0.5, 1.0, 2.0], nobs - 1)
+        tracks.append((name, t))
+    thetas = np.log(np.array([[1.0, 1.0, 0.5], [50.0, 20.0, 0.01], [3.0, 150.0, 1e-3], [1e3, 5.0, 0.2]]))
+    for name, t in tracks:
+        kern = 1.0 * RBF() + WhiteKernel(noise_level=0.5)
+        gp = GPRegression(kernel=kern)
+        model = gp.fit(t, gpr_kwargs={"optimizer": None})
+        lml = []; grad = []
+        for th in thetas:
+            l, g = model.log_marginal_likelihood(th, eval_gradient=True)
+            lml.append(l); grad.append(g)
+        times = np.insert(np.cumsum(t.dts), 0, 0)
+        tq = np.concatenate([times, (times[:-1] + times[1:]) / 2, [times[-1] + 5.0]])
+        preds = []; stds = []
+        for th in thetas[:3]:
+            kern2 = float(np.exp(th[0])) * RBF(float(np.exp(th[1]))) + WhiteKernel(float(np.exp(th[2])))
+            gp2 = GPRegression(kernel=kern2)
+            gp2.fit(t, gpr_kwargs={"optimizer": None})
+            m, sd = gp2.predict(tq)
+            preds.append(m); stds.append(sd)
+        gp3 = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
+        m3 = gp3.fit(t, gpr_kwargs={"n_restarts_optimizer": 3, "random_state": 0})
+        out.update({f"{name}_dts": np.asarray(t.dts), f"{name}_lon": np.asarray(t.lon), f"{name}_lat": np.asarray(t.lat),
+                    f"{name}_lml": np.array(lml), f"{name}_grad": np.array(grad), f"{name}_tq": tq,
+                    f"{name}_pred": np.array(preds), f"{name}_std": np.array(stds),
+                    f"{name}_fit_theta": m3.kernel_.theta, f"{name}_fit_lml": m3.log_marginal_likelihood_value_})
+        print(f"gp {name}: n={len(t.lon)} fit theta={m3.kernel_.theta} lml={m3.log_marginal_likelihood_value_:.6f}")
+    out["thetas"] = thetas
+    return out
+
+
 def csv_fixture():
     """Rows of ship 01203823 cut from the reference's data file (the input of its own CLI example), plus one of the
     header rows the source file repeats between ships, so the id column stays a string column as in the full file."""
@@ -334,6 +380,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ukf_ship_01203823.npz"), **pack_cases(real_case()))
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())
     csv_fixture()
+    np.savez_compressed(os.path.join(HERE, "gp.npz"), **gp_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
