@@ -168,6 +168,58 @@ int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double
 int ste_sigma_points_generic_f64(int32_t n, int64_t count, const double* x, const double* P, double scale, double* out,
                                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Second kernel set: Gaussian-process regression (reference: src/track_estimators/gaussian_processes/
+ * gaussian_process.py:28-89, a wrapper over scikit-learn's GaussianProcessRegressor).  One batch = B independent tracks;
+ * track b has n[b] observations at 1-D inputs x (cumulative time, gaussian_process.py:53-58) with nout outputs
+ * (lon, lat: :66) and its own kernel hyper-parameters theta = log(constant, length_scale, noise) of
+ * ConstantKernel * RBF + WhiteKernel (examples/example_gaussian_process_batch.py:41).
+ * Matrices are row-major [B][ld][ld] with ld = 64 * ceil(nmax / 64); all buffers are caller-owned device memory.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct ste_gp_batch_f64 {
+    int32_t B;     /* number of tracks */
+    int32_t nmax;  /* padded number of observations */
+    int32_t nout;  /* output columns of y (2: lon, lat) */
+    int32_t reserved;
+    double jitter; /* added to the diagonal of K (GaussianProcessRegressor alpha, 1e-10) */
+    const int32_t* n;    /* [B] observations per track */
+    const double* x;     /* [B][nmax] */
+    const double* y;     /* [B][nout][nmax] */
+    const double* theta; /* [B][3] log(constant), log(length_scale), log(noise) */
+    double* K;      /* [B][ld][ld]  K(X,X) + (noise + jitter) I, then its Cholesky factor L (lower triangle) */
+    double* U;      /* [B][ld][ld]  workspace: L^-T (upper triangle) */
+    double* Dinv;   /* [B][ld/64][64][64] workspace: inverses of the diagonal blocks of L */
+    double* Kinv;   /* [B][ld][ld] K^-1 (both triangles) when non-NULL; needed by ste_gp_predict_f64 */
+    double* alpha;  /* [B][nout][nmax] out: K^-1 y */
+    double* lml;    /* [B] out: log marginal likelihood summed over outputs */
+    double* grad;   /* [B][3] out: d lml / d theta, or NULL to skip the gradient */
+    double* tr;     /* [B][3] workspace */
+    int32_t* status; /* [B] out: 0 ok, 1 = K not positive definite */
+} ste_gp_batch_f64;
+
+const char* ste_gp_last_error(void);
+
+/* K(X,X) build only (lower 64x64 tiles + identity padding) -- sklearn kernel __call__ (RBF: exp(-pdist^2/2)). */
+int ste_gp_rbf_kmatrix_f64(const ste_gp_batch_f64* b, void* stream);
+
+/* In-place blocked Cholesky of K (scipy.linalg.cholesky(K, lower=True) in GaussianProcessRegressor). */
+int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream);
+
+/*
+ * One objective evaluation per track (GaussianProcessRegressor.log_marginal_likelihood(theta, eval_gradient=True)):
+ * K build, Cholesky, L^-T, alpha, lml, and -- when grad != NULL -- the gradient via K^-1 = L^-T L^-1 reduced against
+ * dK/dtheta on the fly.
+ */
+int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream);
+
+/*
+ * Posterior mean [B][nout][mmax] and variance [B][mmax] at m[b] new inputs xs [B][mmax]
+ * (GaussianProcessRegressor.predict(return_std=True); std = sqrt(max(var, 0)) is left to the caller).
+ * Needs alpha and Kinv from a preceding ste_gp_lml_f64 on the same batch.  Kstar: workspace [B][64*ceil(mmax/64)][ld].
+ */
+int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m, const double* xs, double* Kstar,
+                       double* mean, double* var, void* stream);
+
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
  *   0 = library default, 1 = one lane per track, 4 = one DPP quad (4 lanes) per track.

@@ -1,0 +1,642 @@
+// ste_gp.hip — second kernel set: Gaussian-process regression on many ship tracks at once (gfx950, fp64).
+//
+// The reference's GPRegression (src/track_estimators/gaussian_processes/gaussian_process.py:28-89) hands X = cumulative
+// time (n x 1) and y = (lon, lat) (n x 2) to scikit-learn's GaussianProcessRegressor with the kernel
+// ConstantKernel * RBF + WhiteKernel (examples/example_gaussian_process_batch.py:41).  Every objective evaluation of its
+// L-BFGS-B fit is: build K(X,X), Cholesky, alpha = K^-1 y, log-marginal likelihood, K^-1, gradient (GPML Alg. 2.1,
+// eq. 5.9).  This file evaluates that objective for a batch of tracks with hand-written kernels:
+//
+//   gp_kbuild      K = c exp(-(xi-xj)^2 / 2 l^2) + (s + jitter) I, lower 64x64 tiles, identity padding
+//   gp_potrf       blocked left-looking Cholesky, one workgroup per matrix, tile products on fp64 MFMA
+//   gp_trtri       U = L^-T (upper, row-major), one workgroup per (matrix, block row)
+//   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised) -> gradient
+//   gp_alpha_lml   alpha = U (U^T y), log-marginal likelihood
+//   gp_kstar / gp_predict   posterior mean and variance at new times (variance as a tile GEMM against K^-1)
+//
+// All dense work is 64x64-tile "NT" products C += A_rows * B_rows^T with both operands row-major and contiguous along
+// the contraction index, issued as v_mfma_f64_16x16x4_f64: lane l feeds A[row l&15][k = l>>4] and B[col l&15][k = l>>4]
+// and each lane loads four consecutive k (32 B), so a wave-level load covers 16 rows x one full 128-B line.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ste.h"
+
+namespace stegp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int T = 64;  // tile edge
+constexpr double kLog2Pi = 1.8378770664093453;
+
+struct GpParams {
+    int B, nmax, nb_max, nout;
+    int ld;  // leading dimension of every n x n buffer = nb_max * 64
+    const int32_t* n;
+    const double* x;      // [B][nmax]
+    const double* y;      // [B][nout][nmax]
+    const double* theta;  // [B][3]
+    double jitter;
+    double* K;      // [B][ld][ld]  K, then L (lower)
+    double* U;      // [B][ld][ld]  L^-T (upper); lower triangle reused for K^-1 when requested
+    double* Dinv;   // [B][nb_max][64][64] inverses of the diagonal blocks of L
+    double* alpha;  // [B][nout][nmax]
+    double* lml;    // [B]
+    double* grad;   // [B][3] or null
+    double* tr;     // [B][3] workspace: tr(K^-1 Krbf), tr(K^-1 (Krbf o D2)), tr(K^-1)
+    int32_t* status;
+    int store_kinv;
+};
+
+__device__ __forceinline__ int nblocks(int n) { return (n + T - 1) / T; }
+
+// One wave accumulates a 32x32 block (2x2 MFMA tiles) of C += A_rows[ra..ra+32) * B_rows[rb..rb+32)^T over k in [k0, k1).
+// acc[mi][ni] holds rows ra + 16 mi + (lane>>4) + 4 reg, col rb + 16 ni + (lane & 15).
+__device__ __forceinline__ void wave_gemm_nt(v4d (&acc)[2][2], const double* __restrict__ A, size_t lda,
+                                             const double* __restrict__ Bm, size_t ldb, int k0, int k1, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const double* pa0 = A + (size_t)r * lda + 4 * g;
+    const double* pa1 = pa0 + 16 * lda;
+    const double* pb0 = Bm + (size_t)r * ldb + 4 * g;
+    const double* pb1 = pb0 + 16 * ldb;
+    for (int k = k0; k < k1; k += 16) {
+        const v4d a0 = *reinterpret_cast<const v4d*>(pa0 + k);
+        const v4d a1 = *reinterpret_cast<const v4d*>(pa1 + k);
+        const v4d b0 = *reinterpret_cast<const v4d*>(pb0 + k);
+        const v4d b1 = *reinterpret_cast<const v4d*>(pb1 + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b1[e], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b0[e], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(v4d (&acc)[2][2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+}
+
+// Visit the 16 elements a lane owns in its wave's 32x32 block: f(row, col, value&), rows/cols relative to the 64x64 tile.
+template <typename F>
+__device__ __forceinline__ void for_each_acc(v4d (&acc)[2][2], int wave, int lane, F f) {
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f(wr + 16 * m + (lane >> 4) + 4 * e, wc + 16 * n + (lane & 15), acc[m][n][e]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K build: lower tiles of K (including the diagonal tiles in full), identity on the padding.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_kbuild(const GpParams p) {
+    const int b = blockIdx.y;
+    const int n = p.n[b];
+    const int nb = nblocks(n);
+    // tile index -> (ti >= tj)
+    int tile = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+    while (ti * (ti + 1) / 2 > tile) --ti;
+    const int tj = tile - ti * (ti + 1) / 2;
+    if (ti >= nb) return;
+    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]), s = exp(p.theta[b * 3 + 2]);
+    const double* x = p.x + (size_t)b * p.nmax;
+    double* K = p.K + (size_t)b * p.ld * p.ld;
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int r = ti * T + e / T, cidx = tj * T + e % T;
+        double v;
+        if (r < n && cidx < n) {
+            const double d = (x[r] - x[cidx]) * inv_l;
+            v = c * exp(-0.5 * d * d);
+            if (r == cidx) v += s + p.jitter;
+        } else {
+            v = (r == cidx) ? 1.0 : 0.0;
+        }
+        K[(size_t)r * p.ld + cidx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64x64 diagonal-block kernels in LDS (row-major, leading dimension 65 to spread banks)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LD = T + 1;
+
+// In-place Cholesky of the lower triangle of S (64x64); returns false through *ok if a pivot is not positive.
+__device__ void chol64(double* S, int tid, int* ok) {
+    for (int c = 0; c < T; ++c) {
+        __syncthreads();
+        const double d = S[c * LD + c];
+        if (!(d > 0.0)) {
+            if (tid == 0) *ok = 0;
+        }
+        const double rd = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+        __syncthreads();
+        for (int r = c + tid; r < T; r += 256) S[r * LD + c] = (r == c) ? d * rd : S[r * LD + c] * rd;
+        __syncthreads();
+        // trailing update of the lower triangle: S[r][cc] -= S[r][c] * S[cc][c], r >= cc > c
+        const int m = T - 1 - c;
+        for (int e = tid; e < m * m; e += 256) {
+            const int r = c + 1 + e / m, cc = c + 1 + e % m;
+            if (cc <= r) S[r * LD + cc] -= S[r * LD + c] * S[cc * LD + c];
+        }
+    }
+    __syncthreads();
+}
+
+// X = L^-1 for the lower-triangular L in S (64x64), written to X (LDS, same layout); 64 threads, one column each.
+__device__ void trinv64(const double* S, double* X, int tid) {
+    if (tid < T) {
+        const int c = tid;
+        for (int r = 0; r < T; ++r) {
+            double acc = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) acc -= S[r * LD + k] * X[k * LD + c];
+            X[r * LD + c] = (r < c) ? 0.0 : acc / S[r * LD + r];
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked left-looking Cholesky, one workgroup (4 waves) per matrix.  L overwrites the lower triangle of K.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_potrf(const GpParams p) {
+    __shared__ double S[T * LD];
+    __shared__ double X[T * LD];
+    __shared__ int ok;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = nblocks(p.n[b]);
+    const size_t ld = p.ld;
+    double* K = p.K + (size_t)b * ld * ld;
+    double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    for (int i = 0; i < nb; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            v4d acc[2][2];
+            zero_acc(acc);
+            wave_gemm_nt(acc, K + (size_t)(i * T + wr) * ld, ld, K + (size_t)(j * T + wc) * ld, ld, 0, j * T, lane);
+            // C = A[i][j] - acc  -> LDS
+            for_each_acc(acc, wave, lane, [&](int r, int c, double v) {
+                S[r * LD + c] = K[(size_t)(i * T + r) * ld + j * T + c] - v;
+            });
+            __syncthreads();
+            if (j < i) {
+                // L[i][j] = C * Dinv_j^T   (NT product with A = C in LDS, B = Dinv_j in global)
+                v4d a2[2][2];
+                zero_acc(a2);
+                const int r = lane & 15, g = lane >> 4;
+                const double* Dj = Dinv + (size_t)j * T * T;
+                for (int k = 0; k < T; k += 16) {
+                    double a0[4], a1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0[e] = S[(wr + r) * LD + k + 4 * g + e];
+                        a1[e] = S[(wr + 16 + r) * LD + k + 4 * g + e];
+                    }
+                    const v4d b0 = *reinterpret_cast<const v4d*>(Dj + (size_t)(wc + r) * T + k + 4 * g);
+                    const v4d b1 = *reinterpret_cast<const v4d*>(Dj + (size_t)(wc + 16 + r) * T + k + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], a2[0][0], 0, 0, 0);
+                        a2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b1[e], a2[0][1], 0, 0, 0);
+                        a2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b0[e], a2[1][0], 0, 0, 0);
+                        a2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], a2[1][1], 0, 0, 0);
+                    }
+                }
+                for_each_acc(a2, wave, lane, [&](int rr, int cc, double v) {
+                    K[(size_t)(i * T + rr) * ld + j * T + cc] = v;
+                });
+            } else {
+                chol64(S, tid, &ok);
+                trinv64(S, X, tid);
+                for (int e = tid; e < T * T; e += 256) {
+                    const int r = e / T, c = e % T;
+                    if (c <= r) K[(size_t)(i * T + r) * ld + i * T + c] = S[r * LD + c];
+                    Dinv[(size_t)i * T * T + e] = X[r * LD + c];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    if (tid == 0) p.status[b] = ok ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// U = L^-T (upper triangular, row-major).  Row block a of U depends only on L and Dinv: one workgroup per (a, matrix).
+//   U[a][a] = Dinv_a^T ;  U[a][b] = -( sum_{k in [a, b)} U[a][k] L[b][k]^T ) Dinv_b^T   for b > a
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
+    __shared__ double S[T * LD];
+    const int b = blockIdx.y, a = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = nblocks(p.n[b]);
+    if (a >= nb) return;
+    const size_t ld = p.ld;
+    const double* L = p.K + (size_t)b * ld * ld;
+    double* U = p.U + (size_t)b * ld * ld;
+    const double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    for (int e = tid; e < T * T; e += 256) {
+        const int r = e / T, c = e % T;
+        U[(size_t)(a * T + r) * ld + a * T + c] = Dinv[(size_t)a * T * T + (size_t)c * T + r];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int bb = a + 1; bb < nb; ++bb) {
+        v4d acc[2][2];
+        zero_acc(acc);
+        wave_gemm_nt(acc, U + (size_t)(a * T + wr) * ld, ld, L + (size_t)(bb * T + wc) * ld, ld, a * T, bb * T, lane);
+        for_each_acc(acc, wave, lane, [&](int r, int c, double v) { S[r * LD + c] = -v; });
+        __syncthreads();
+        v4d a2[2][2];
+        zero_acc(a2);
+        const int r = lane & 15, g = lane >> 4;
+        const double* Db = Dinv + (size_t)bb * T * T;
+        for (int k = 0; k < T; k += 16) {
+            double a0[4], a1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = S[(wr + r) * LD + k + 4 * g + e];
+                a1[e] = S[(wr + 16 + r) * LD + k + 4 * g + e];
+            }
+            const v4d b0 = *reinterpret_cast<const v4d*>(Db + (size_t)(wc + r) * T + k + 4 * g);
+            const v4d b1 = *reinterpret_cast<const v4d*>(Db + (size_t)(wc + 16 + r) * T + k + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], a2[0][0], 0, 0, 0);
+                a2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b1[e], a2[0][1], 0, 0, 0);
+                a2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b0[e], a2[1][0], 0, 0, 0);
+                a2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], a2[1][1], 0, 0, 0);
+            }
+        }
+        for_each_acc(a2, wave, lane, [&](int rr, int cc, double v) {
+            U[(size_t)(a * T + rr) * ld + bb * T + cc] = v;
+        });
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K^-1 tile (ta >= tb) = sum_{k >= ta} U[ta][k] U[tb][k]^T, reduced against the kernel derivatives:
+//   tr[0] += sum Kinv * Krbf,  tr[1] += sum Kinv * Krbf * d^2,  tr[2] += trace(Kinv)      (off-diagonal tiles count twice)
+// Optionally stores K^-1 (both triangles) into the lower/upper... into `kinv_out` for the predictive variance.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* kinv_out) {
+    __shared__ double red[3][4];
+    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = p.n[b], nb = nblocks(n);
+    int tile = blockIdx.x;
+    int ta = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+    while (ta * (ta + 1) / 2 > tile) --ta;
+    const int tb = tile - ta * (ta + 1) / 2;
+    if (ta >= nb) return;
+    const size_t ld = p.ld;
+    const double* U = p.U + (size_t)b * ld * ld;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    v4d acc[2][2];
+    zero_acc(acc);
+    wave_gemm_nt(acc, U + (size_t)(ta * T + wr) * ld, ld, U + (size_t)(tb * T + wc) * ld, ld, ta * T, nb * T, lane);
+    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
+    const double* x = p.x + (size_t)b * p.nmax;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    const double wgt = (ta == tb) ? 1.0 : 2.0;
+    for_each_acc(acc, wave, lane, [&](int r, int cc, double v) {
+        const int gr = ta * T + r, gc = tb * T + cc;
+        if (gr < n && gc < n) {
+            const double d = (x[gr] - x[gc]) * inv_l;
+            const double d2 = d * d;
+            const double kr = c * exp(-0.5 * d2);
+            t0 += wgt * v * kr;
+            t1 += wgt * v * kr * d2;
+            if (gr == gc) t2 += v;
+        }
+        if (kinv_out) {
+            kinv_out[(size_t)b * ld * ld + (size_t)gr * ld + gc] = v;
+            kinv_out[(size_t)b * ld * ld + (size_t)gc * ld + gr] = v;
+        }
+    });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        t0 += __shfl_xor(t0, off);
+        t1 += __shfl_xor(t1, off);
+        t2 += __shfl_xor(t2, off);
+    }
+    if (lane == 0) {
+        red[0][wave] = t0;
+        red[1][wave] = t1;
+        red[2][wave] = t2;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        const double v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        atomicAdd(&p.tr[b * 3 + tid], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// alpha = U (U^T y), lml, gradient assembly.  One workgroup per matrix; n^2 work, memory bound.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_alpha_lml(const GpParams p) {
+    extern __shared__ double sh[];  // w[nout][npad]
+    __shared__ double red[8][4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = p.n[b], nb = nblocks(n), npad = nb * T;
+    const size_t ld = p.ld;
+    const double* U = p.U + (size_t)b * ld * ld;
+    const double* L = p.K + (size_t)b * ld * ld;
+    const double* x = p.x + (size_t)b * p.nmax;
+    const int nout = p.nout;
+    // w = U^T y : w[k] = sum_{a <= k} U[a][k] y[a]   (thread per column k: coalesced across the wave)
+    for (int o = 0; o < nout; ++o) {
+        const double* y = p.y + ((size_t)b * nout + o) * p.nmax;
+        for (int k = tid; k < npad; k += 256) {
+            double acc = 0.0;
+            const int amax = k < n ? k : n - 1;
+            for (int a = 0; a <= amax; ++a) acc = fma(U[(size_t)a * ld + k], y[a], acc);
+            sh[o * npad + k] = acc;
+        }
+    }
+    __syncthreads();
+    // alpha[a] = sum_{k >= a} U[a][k] w[k]   (wave per row)
+    double yta = 0.0;  // sum_o y_o . alpha_o
+    for (int o = 0; o < nout; ++o) {
+        const double* y = p.y + ((size_t)b * nout + o) * p.nmax;
+        double* al = p.alpha + ((size_t)b * nout + o) * p.nmax;
+        for (int a = wave; a < n; a += 4) {
+            double acc = 0.0;
+            for (int k = a + lane; k < npad; k += 64) acc = fma(U[(size_t)a * ld + k], sh[o * npad + k], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) {
+                al[a] = acc;
+                yta += y[a] * acc;
+            }
+        }
+    }
+    // sum log diag L
+    double sl = 0.0;
+    for (int i = tid; i < n; i += 256) sl += log(L[(size_t)i * ld + i]);
+    // alpha^T G alpha for the two RBF derivatives (n^2 exps) and alpha.alpha for the noise term
+    __syncthreads();
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    if (p.grad) {
+        const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
+        for (int o = 0; o < nout; ++o) {
+            const double* al = p.alpha + ((size_t)b * nout + o) * p.nmax;
+            for (int i = wave; i < n; i += 4) {
+                const double ai = al[i], xi = x[i];
+                double r0 = 0.0, r1 = 0.0;
+                for (int j = lane; j < n; j += 64) {
+                    const double d = (xi - x[j]) * inv_l, d2 = d * d;
+                    const double kr = c * exp(-0.5 * d2) * al[j];
+                    r0 += kr;
+                    r1 += kr * d2;
+                }
+                q0 += ai * r0;
+                q1 += ai * r1;
+                if (lane == 0) q2 += ai * ai;
+            }
+        }
+    }
+    double vals[6] = {yta, sl, q0, q1, q2, 0.0};
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        double t = vals[v];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0) red[v][wave] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double r[5];
+        for (int v = 0; v < 5; ++v) r[v] = red[v][0] + red[v][1] + red[v][2] + red[v][3];
+        p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
+        if (p.grad) {
+            const double s = exp(p.theta[b * 3 + 2]);
+            p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * p.tr[b * 3 + 0]);
+            p.grad[b * 3 + 1] = 0.5 * (r[3] - nout * p.tr[b * 3 + 1]);
+            p.grad[b * 3 + 2] = 0.5 * s * (r[4] - nout * p.tr[b * 3 + 2]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Prediction: Kstar[m][i] = c exp(-(xs_m - x_i)^2 / 2 l^2) (padded to tiles with zeros), mean = Kstar alpha,
+// var_m = c + s - kstar_m^T K^-1 kstar_m as tile products W = Kstar K^-1 reduced against Kstar on the fly.
+// ---------------------------------------------------------------------------------------------------------------
+struct GpPredict {
+    int B, mmax, mb_max, ldk;  // ldk = leading dim of Kstar rows (= ld of the n x n buffers)
+    const int32_t* m;
+    const double* xs;  // [B][mmax]
+    double* Kstar;     // [B][mb_max*64][ldk]
+    const double* Kinv;
+    double* mean;  // [B][nout][mmax]
+    double* var;   // [B][mmax]
+};
+
+__global__ __launch_bounds__(256) void gp_kstar(const GpParams p, const GpPredict q) {
+    const int b = blockIdx.y, mt = blockIdx.x;
+    const int n = p.n[b], m = q.m[b];
+    if (mt * T >= ((m + T - 1) / T) * T) return;
+    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
+    const double* x = p.x + (size_t)b * p.nmax;
+    const double* xs = q.xs + (size_t)b * q.mmax;
+    double* Ks = q.Kstar + (size_t)b * q.mb_max * T * q.ldk;
+    const int npad = nblocks(n) * T;
+    for (int r = 0; r < T; ++r) {
+        const int gm = mt * T + r;
+        for (int i = threadIdx.x; i < npad; i += 256) {
+            double v = 0.0;
+            if (gm < m && i < n) {
+                const double d = (xs[gm] - x[i]) * inv_l;
+                v = c * exp(-0.5 * d * d);
+            }
+            Ks[(size_t)gm * q.ldk + i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_predict(const GpParams p, const GpPredict q) {
+    __shared__ double rowsum[T][2];
+    const int b = blockIdx.y, mt = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = p.n[b], m = q.m[b], nb = nblocks(n);
+    if (mt * T >= m) return;
+    const size_t ld = p.ld;
+    const double* Ks = q.Kstar + (size_t)b * q.mb_max * T * q.ldk;
+    const double* Kinv = q.Kinv + (size_t)b * ld * ld;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    double part[8];  // per-lane partial of sum_i W[m][i] Kstar[m][i] for the 8 rows this lane touches (2 m-blocks x 4 regs)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[e] = 0.0;
+    for (int it = 0; it < nb; ++it) {
+        v4d acc[2][2];
+        zero_acc(acc);
+        wave_gemm_nt(acc, Ks + (size_t)(mt * T + wr) * q.ldk, q.ldk, Kinv + (size_t)(it * T + wc) * ld, ld, 0, nb * T, lane);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = wr + 16 * mi + (lane >> 4) + 4 * e, c = wc + 16 * ni + (lane & 15);
+                    part[mi * 4 + e] += acc[mi][ni][e] * Ks[(size_t)(mt * T + r) * q.ldk + it * T + c];
+                }
+    }
+    // reduce over the 16 lanes that share a row (lane & 15), then over the two waves that share the row block
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        double t = part[e];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        part[e] = t;
+    }
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowsum[wr + 16 * mi + (lane >> 4) + 4 * e][wave & 1] = part[mi * 4 + e];
+    }
+    __syncthreads();
+    const double c = exp(p.theta[b * 3 + 0]), s = exp(p.theta[b * 3 + 2]);
+    if (tid < T) {
+        const int gm = mt * T + tid;
+        if (gm < m) q.var[(size_t)b * q.mmax + gm] = (c + s) - (rowsum[tid][0] + rowsum[tid][1]);
+    }
+    // mean: wave per row, lanes over i
+    for (int o = 0; o < p.nout; ++o) {
+        const double* al = p.alpha + ((size_t)b * p.nout + o) * p.nmax;
+        for (int r = wave; r < T; r += 4) {
+            const int gm = mt * T + r;
+            if (gm >= m) continue;
+            double acc = 0.0;
+            for (int i = lane; i < n; i += 64) acc = fma(Ks[(size_t)gm * q.ldk + i], al[i], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) q.mean[((size_t)b * p.nout + o) * q.mmax + gm] = acc;
+        }
+    }
+}
+
+}  // namespace stegp
+
+// ===============================================================================================================
+// C ABI
+// ===============================================================================================================
+namespace {
+thread_local char g_gp_err[256] = "";
+int gp_fail(const char* m) {
+    snprintf(g_gp_err, sizeof(g_gp_err), "%s", m);
+    return STE_EINVAL;
+}
+int gp_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return STE_OK;
+    snprintf(g_gp_err, sizeof(g_gp_err), "%s: %s", what, hipGetErrorString(e));
+    return STE_ELAUNCH;
+}
+int gp_params(const ste_gp_batch_f64* b, stegp::GpParams* p) {
+    if (!b) return gp_fail("gp batch pointer is NULL");
+    if (b->B <= 0 || b->nmax <= 0) return gp_fail("B and nmax must be > 0");
+    if (b->nout < 1 || b->nout > 4) return gp_fail("nout must be in 1..4");
+    if (!b->n || !b->x || !b->y || !b->theta || !b->K || !b->U || !b->Dinv || !b->alpha || !b->lml || !b->tr || !b->status)
+        return gp_fail("n, x, y, theta, K, U, Dinv, alpha, lml, tr and status are required");
+    p->B = b->B;
+    p->nmax = b->nmax;
+    p->nb_max = (b->nmax + 63) / 64;
+    p->nout = b->nout;
+    p->ld = p->nb_max * 64;
+    p->n = b->n;
+    p->x = b->x;
+    p->y = b->y;
+    p->theta = b->theta;
+    p->jitter = b->jitter;
+    p->K = b->K;
+    p->U = b->U;
+    p->Dinv = b->Dinv;
+    p->alpha = b->alpha;
+    p->lml = b->lml;
+    p->grad = b->grad;
+    p->tr = b->tr;
+    p->status = b->status;
+    p->store_kinv = 0;
+    return STE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ste_gp_last_error(void) { return g_gp_err; }
+
+int ste_gp_rbf_kmatrix_f64(const ste_gp_batch_f64* b, void* stream) {
+    stegp::GpParams p;
+    int rc = gp_params(b, &p);
+    if (rc) return rc;
+    const int tiles = p.nb_max * (p.nb_max + 1) / 2;
+    hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, p.B), dim3(256), 0, (hipStream_t)stream, p);
+    return gp_hip(hipGetLastError(), "gp_kbuild launch");
+}
+
+int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream) {
+    stegp::GpParams p;
+    int rc = gp_params(b, &p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    return gp_hip(hipGetLastError(), "gp_potrf launch");
+}
+
+int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
+    stegp::GpParams p;
+    int rc = gp_params(b, &p);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = p.nb_max * (p.nb_max + 1) / 2;
+    rc = gp_hip(hipMemsetAsync(p.tr, 0, sizeof(double) * 3 * p.B, s), "memset tr");
+    if (rc) return rc;
+    hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_trtri, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
+    if (p.grad || b->Kinv) hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(tiles, p.B), dim3(256), 0, s, p, b->Kinv);
+    const size_t shmem = sizeof(double) * (size_t)p.nout * p.ld;
+    hipLaunchKernelGGL(stegp::gp_alpha_lml, dim3(p.B), dim3(256), shmem, s, p);
+    return gp_hip(hipGetLastError(), "gp_lml launch");
+}
+
+int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m, const double* xs, double* Kstar,
+                       double* mean, double* var, void* stream) {
+    stegp::GpParams p;
+    int rc = gp_params(b, &p);
+    if (rc) return rc;
+    if (mmax <= 0 || !m || !xs || !Kstar || !mean || !var || !b->Kinv)
+        return gp_fail("mmax > 0, m, xs, Kstar, mean, var and batch.Kinv are required (run ste_gp_lml_f64 with Kinv set first)");
+    stegp::GpPredict q;
+    q.B = p.B;
+    q.mmax = mmax;
+    q.mb_max = (mmax + 63) / 64;
+    q.ldk = p.ld;
+    q.m = m;
+    q.xs = xs;
+    q.Kstar = Kstar;
+    q.Kinv = b->Kinv;
+    q.mean = mean;
+    q.var = var;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(stegp::gp_kstar, dim3(q.mb_max, p.B), dim3(256), 0, s, p, q);
+    hipLaunchKernelGGL(stegp::gp_predict, dim3(q.mb_max, p.B), dim3(256), 0, s, p, q);
+    return gp_hip(hipGetLastError(), "gp_predict launch");
+}
+
+}  // extern "C"

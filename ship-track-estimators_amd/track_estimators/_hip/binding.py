@@ -62,6 +62,31 @@ class SteUkfBatchF64(C.Structure):
     ]
 
 
+class SteGpBatchF64(C.Structure):
+    """Mirror of ``struct ste_gp_batch_f64`` (include/ste.h)."""
+
+    _fields_ = [
+        ("B", C.c_int32),
+        ("nmax", C.c_int32),
+        ("nout", C.c_int32),
+        ("reserved", C.c_int32),
+        ("jitter", C.c_double),
+        ("n", _dp),
+        ("x", _dp),
+        ("y", _dp),
+        ("theta", _dp),
+        ("K", _dp),
+        ("U", _dp),
+        ("Dinv", _dp),
+        ("Kinv", _dp),
+        ("alpha", _dp),
+        ("lml", _dp),
+        ("grad", _dp),
+        ("tr", _dp),
+        ("status", _dp),
+    ]
+
+
 # every symbol include/ste.h declares: (restype, argtypes)
 SYMBOLS = {
     "ste_version": (C.c_int, []),
@@ -76,6 +101,11 @@ SYMBOLS = {
     "ste_ukf_update_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_sigma_points_f64": (C.c_int, [C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
     "ste_sigma_points_generic_f64": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
+    "ste_gp_last_error": (C.c_char_p, []),
+    "ste_gp_rbf_kmatrix_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
+    "ste_gp_potrf_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
+    "ste_gp_lml_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
+    "ste_gp_predict_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
 }
 
@@ -113,7 +143,8 @@ def load():
 
 def check(rc: int, what: str):
     if rc != 0:
-        msg = load().ste_last_error()
+        lib = load()
+        msg = lib.ste_gp_last_error() if what.startswith("ste_gp") else lib.ste_last_error()
         raise SteError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 

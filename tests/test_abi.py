@@ -26,10 +26,11 @@ def test_struct_layout_matches_header():
     from track_estimators._hip import binding
 
     hdr = open(os.path.join(ROOT, "include", "ste.h")).read()
-    body = hdr[hdr.index("typedef struct ste_ukf_batch_f64 {"): hdr.index("} ste_ukf_batch_f64;")]
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|double)\s*\*?\s*(\w+)\s*;", body)
-    assert fields == [f[0] for f in binding.SteUkfBatchF64._fields_]
+    for cname, mirror in (("ste_ukf_batch_f64", binding.SteUkfBatchF64), ("ste_gp_batch_f64", binding.SteGpBatchF64)):
+        body = hdr[hdr.index("typedef struct %s {" % cname): hdr.index("} %s;" % cname)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|double)\s*\*?\s*(\w+)\s*;", body)
+        assert fields == [f[0] for f in mirror._fields_], cname
     assert C.sizeof(binding.SteUkfBatchF64) == 24 + 3 * 8 + 22 * 8
 
 

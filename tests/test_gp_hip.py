@@ -1,0 +1,119 @@
+"""GP kernel set (csrc/ste_gp.hip) through the C ABI vs the goldens from the reference's GPRegression and the oracle."""
+import os
+
+import numpy as np
+import pytest
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["ship", "syn130", "syn300"]
+
+
+def _data(g, name):
+    x = np.insert(np.cumsum(g[f"{name}_dts"]), 0, 0)
+    y = np.column_stack([g[f"{name}_lon"], g[f"{name}_lat"]])
+    return x, y
+
+
+def test_kmatrix_and_cholesky_vs_oracle():
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    data = [_data(g, n) for n in NAMES]
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data])
+    th = g["thetas"][1]
+    K = batch.kmatrix(np.tile(th, (3, 1)))
+    L, status = batch.cholesky()
+    assert not status.any()
+    for b, (x, y) in enumerate(data):
+        n = len(x)
+        Kref, _ = gpo.kernel_matrix(th, x)
+        Kref[np.diag_indices_from(Kref)] += gpo.JITTER
+        np.testing.assert_allclose(np.tril(K[b, :n, :n]), np.tril(Kref), rtol=1e-13, atol=1e-13)
+        Lref = np.linalg.cholesky(Kref)
+        np.testing.assert_allclose(L[b, :n, :n], Lref, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_lml_and_gradient_vs_reference(batched):
+    """Ragged batch (n = 52, 130, 300 -> 1, 3, 5 tiles) at four thetas, vs scikit-learn through the reference wrapper."""
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    data = [_data(g, n) for n in NAMES]
+    groups = [[0, 1, 2]] if batched else [[0], [1], [2]]
+    for grp in groups:
+        batch = GpDeviceBatch([data[i][0] for i in grp], [data[i][1] for i in grp])
+        for t, th in enumerate(g["thetas"]):
+            lml, grad, status = batch.objective(np.tile(th, (len(grp), 1)))
+            assert not status.any()
+            for k, i in enumerate(grp):
+                assert np.isclose(lml[k], g[f"{NAMES[i]}_lml"][t], rtol=1e-9, atol=1e-7)
+                np.testing.assert_allclose(grad[k], g[f"{NAMES[i]}_grad"][t], rtol=1e-6, atol=1e-5)
+
+
+def test_predict_vs_reference():
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    data = [_data(g, n) for n in NAMES]
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data])
+    for t, th in enumerate(g["thetas"][:3]):
+        out = batch.predict(np.tile(th, (3, 1)), [g[f"{n}_tq"] for n in NAMES])
+        for b, n in enumerate(NAMES):
+            np.testing.assert_allclose(out[b][0], g[f"{n}_pred"][t], rtol=1e-8, atol=1e-7)
+            np.testing.assert_allclose(out[b][1], g[f"{n}_std"][t], rtol=1e-5, atol=1e-6)
+
+
+def test_not_positive_definite_is_reported():
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    x = np.array([0.0, 1.0, 1.0, 2.0])  # duplicate input + no noise -> singular K
+    batch = GpDeviceBatch([x], [np.zeros((4, 2))], jitter=0.0)
+    lml, grad, status = batch.objective(np.log([[1.0, 1.0, 1e-300]]))
+    assert status[0] == 1 and lml[0] == -np.inf and not grad.any()
+
+
+def test_gpregression_api_fit_and_predict():
+    """GPRegression.fit / predict (drop-in) on ship 01203823 with a seeded fit, vs the reference's seeded fit."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from track_estimators.gaussian_processes.gaussian_process import GPRegression
+    from track_estimators.ship_track import ShipTrack
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    st = ShipTrack()
+    st.dts, st.lon, st.lat = g["ship_dts"], g["ship_lon"], g["ship_lat"]
+    gp = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
+    model = gp.fit(st, gpr_kwargs={"n_restarts_optimizer": 3, "random_state": 0})
+    assert np.isclose(model.log_marginal_likelihood_value_, g["ship_fit_lml"], rtol=1e-6)
+    np.testing.assert_allclose(model.kernel_.theta, g["ship_fit_theta"], rtol=1e-3, atol=1e-3)
+    pred, std = gp.predict(g["ship_tq"])
+    assert pred.shape == (len(g["ship_tq"]), 2) and std.shape == pred.shape
+    with pytest.raises(NotImplementedError):
+        GPRegression(kernel=RBF()).fit(st, gpr_kwargs={"optimizer": None})
+    with pytest.raises(AssertionError):
+        GPRegression(kernel=RBF()).predict(np.zeros(3))
+
+
+def test_fit_batch_lockstep_matches_single_fits():
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from track_estimators.gaussian_processes.gaussian_process import GPRegression
+    from track_estimators.ship_track import ShipTrack
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    tracks = []
+    for n in NAMES:
+        st = ShipTrack()
+        st.dts, st.lon, st.lat = g[f"{n}_dts"], g[f"{n}_lon"], g[f"{n}_lat"]
+        tracks.append(st)
+    gp = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
+    thetas, lml = gp.fit_batch(tracks, gpr_kwargs={"n_restarts_optimizer": 0})
+    for b, n in enumerate(NAMES):
+        single = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
+        m = single.fit(tracks[b], gpr_kwargs={"n_restarts_optimizer": 0})
+        assert np.isclose(lml[b], m.log_marginal_likelihood_value_, rtol=1e-8)
+        np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-6, atol=1e-6)
+    preds = gp.predict_batch([g[f"{n}_tq"] for n in NAMES])
+    assert all(p[0].shape == (len(g[f"{n}_tq"]), 2) for p, n in zip(preds, NAMES))
