@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""
+bench_gp.py — BASELINE.json configs[4]: GP-regression objective (RBF K-matrix build + Cholesky + gradient) for a batch
+of tracks on one MI355X, beside scikit-learn's algorithm on the host.  Not the headline metric (that is bench.py); one
+JSON line with the same roofline / cpu_baseline objects.
+
+  python bench_gp.py --tracks 1000 --nobs 2000 --evals 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ship-track-estimators_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (= vector peak on CDNA4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tracks", type=int, default=1000)
+    ap.add_argument("--nobs", type=int, default=2000)
+    ap.add_argument("--evals", type=int, default=3)
+    ap.add_argument("--cpu-evals", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    from track_estimators import synthetic
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    B, n = args.tracks, args.nobs
+    sb = synthetic.make_batch(B, nobs=n, gap_h=1.0, seed0=0)
+    xs = [np.insert(np.cumsum(sb.dts[b]), 0, 0) for b in range(B)]
+    ys = [np.column_stack([sb.lon[b], sb.lat[b]]) for b in range(B)]
+    batch = GpDeviceBatch(xs, ys)
+    theta = np.tile(np.log([50.0, 20.0, 0.01]), (B, 1))
+    batch.objective(theta)  # warm-up
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.evals):
+        lml, grad, status = batch.objective(theta)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.evals
+    flops = B * (float(n) ** 3)  # potrf n^3/3 + L^-T n^3/3 + K^-1 n^3/3
+    out = {
+        "metric": "GP objective evaluations/sec (LML + gradient, RBF+White kernel)", "value": B / (ms * 1e-3),
+        "unit": "track-objectives/s", "n_gpus": 1, "ms_per_step": ms, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{B} tracks x {n} observations, K build + Cholesky + L^-T + K^-1-trace gradient "
+                               "(BASELINE.json configs[4])"},
+        "status_flagged": int((status != 0).sum()),
+        "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flops_per_objective": float(n) ** 3},
+    }
+    if args.cpu_evals > 0:
+        from oracle import gp_oracle as gpo
+
+        t0 = time.perf_counter()
+        for k in range(args.cpu_evals):
+            l, g, _, _ = gpo.lml_and_grad(theta[k], xs[k], ys[k])
+        dt = (time.perf_counter() - t0) / args.cpu_evals
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "track-objectives/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{args.cpu_evals} objective evaluations at n={n} (oracle/gp_oracle.py: SciPy "
+                                         "LAPACK cholesky/cho_solve, the same calls scikit-learn makes), BLAS threads = all",
+                               "gpu_vs_oracle_rel_err_lml": float(abs(lml[args.cpu_evals - 1] - l) / abs(l))}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

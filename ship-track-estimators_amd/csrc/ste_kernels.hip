@@ -16,14 +16,9 @@
 
 #include "../../include/ste.h"
 #include "ste_math.h"
+#include "ste_quad.h"
 
 namespace ste {
-
-// Filter constants shared by every track: kernel arguments, so they sit in SGPRs / the scalar cache.
-struct Mats {
-    double fan_scale, w0, wi;
-    double H[16], Q[16], R[16];
-};
 
 struct KParams {
     int B, Nmax, Tmax;
@@ -450,6 +445,230 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
     p.status[t] = st;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward pass, one DPP quad per track (ste_quad.h)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tri_index(int r, int c) { return r * 4 - (r * (r - 1)) / 2 + (c - r); }  // r <= c
+
+// Predict for a quad (unscented.py:178-207) and, when `work` is given, the smoother's x_b, P_b, D of this step.
+// With T = sqrtm(scale P) the cross-covariance is D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T (the centre's deviation is
+// zero and x_b cancels in the difference), and P_b, which is centred on x_k instead of on the predicted mean, follows
+// from the predicted covariance by P_b = P^- + e b^T + b e^T + b b^T with b = x^- - x_k and e = (weighted mean) - x^-
+// (= minus the injected predict noise; zero in noise-free runs), because the weights sum to one.
+__device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
+                                            QuadBasis& basis, double dt, double sr, double cr, const double* noise,
+                                            const double* noise_rts, double* work, size_t nrow, size_t B, size_t t) {
+    double Tn[4], s0[4], sp[4], sm[4], m[4], xp[4];
+    int st = quad_sym_sqrt(Px, p.fan_scale, cx, basis, Tn);
+    quad_propagate(x, Tn, dt, sr, cr, s0, sp, sm);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) m[c] = fma(p.w0, s0[c], p.wi * quad_sum(sp[c] + sm[c]));
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xp[c] = m[c];
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) xp[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    double Pn[4];
+    quad_scatter(s0, sp, sm, xp, p.w0, p.wi, cx, Pn);
+    if (work) {
+        const int q = cx.q;
+        double xb[4], dlt[4], D[4], bv[4], bx[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            xb[c] = m[c];
+            dlt[c] = sp[c] - sm[c];
+            bv[c] = xp[c] - x[c];
+        }
+        if (noise_rts) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) xb[c] += noise_rts[(nrow * 4 + c) * B + t];
+        }
+        quad_mm_rows(Tn, dlt, D);
+        xorperm(bv, q, bx);
+        double Pb[4];
+        STE_UNROLL
+        for (int s = 0; s < 4; ++s) Pb[s] = fma(bx[0], bx[s], Pn[s]);
+        if (noise) {
+            double ev[4], ex[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) ev[c] = m[c] - xp[c];
+            xorperm(ev, q, ex);
+            STE_UNROLL
+            for (int s = 0; s < 4; ++s) Pb[s] += fma(ex[0], bx[s], bx[0] * ex[s]);
+        }
+        double* w = work + (nrow * kWorkElems) * B + t;
+        w[(kWorkXb + q) * B] = sel4(xb, q);
+        STE_UNROLL
+        for (int s = 0; s < 4; ++s) {
+            const int c = q ^ s;
+            if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pb[s];
+        }
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) w[(kWorkK + q * 4 + c) * B] = p.wi * D[c];
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        x[c] = xp[c];
+        Px[c] = Pn[c];
+    }
+    return st;
+}
+
+// Measurement update for a quad (unscented.py:219-265): every 4x4 product is one row per lane, rows of the other
+// operand arrive by quad broadcasts.
+__device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
+                                           const double (&zin)[4], const double* noise, size_t nrow, size_t B,
+                                           size_t t) {
+    const int q = cx.q;
+    double z[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) z[c] = zin[c];
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    // G = P H^T (row q): G[c] = sum_k P[q][q^k] H[c][q^k]
+    double G[4], Sn[4], Sin[4], K[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        double acc = Px[0] * cx.HTx[c][0];
+        STE_UNROLL
+        for (int k = 1; k < 4; ++k) acc = fma(Px[k], cx.HTx[c][k], acc);
+        G[c] = acc;
+    }
+    quad_mm_rows(cx.Hrow, G, Sn);  // S = H G + R
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) Sn[c] += cx.Rrow[c];
+    const int st = quad_sym_pinv(Sn, cx, Sin);
+    quad_mm_rows(G, Sin, K);  // K = G S^+  (row q)
+    double y[4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        double hx = p.H[r * 4 + 0] * x[0];
+        STE_UNROLL
+        for (int c = 1; c < 4; ++c) hx = fma(p.H[r * 4 + c], x[c], hx);
+        y[r] = z[r] - hx;
+    }
+    y[3] = wrap180(y[3]);
+    double xq = sel4(x, q);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xq = fma(K[c], y[c], xq);
+    x[0] = bcast<0>(xq);
+    x[1] = bcast<1>(xq);
+    x[2] = bcast<2>(xq);
+    x[3] = floored_mod(bcast<3>(xq), 360.0);
+    // Joseph form: A = I - K H, P = A P A^T + K R K^T
+    double A[4], KR[4], Pnat[4], AP[4], P1[4], P2[4], Pnew[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        double kh = K[0] * p.H[0 * 4 + c], kr = K[0] * p.R[0 * 4 + c];
+        STE_UNROLL
+        for (int l = 1; l < 4; ++l) {
+            kh = fma(K[l], p.H[l * 4 + c], kh);
+            kr = fma(K[l], p.R[l * 4 + c], kr);
+        }
+        A[c] = ((c == q) ? 1.0 : 0.0) - kh;
+        KR[c] = kr;
+    }
+    xorperm(Px, q, Pnat);
+    quad_mm_rows(A, Pnat, AP);
+    quad_mm_rows_t(AP, A, P1);
+    quad_mm_rows_t(KR, K, P2);
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) Pnew[c] = P1[c] + P2[c];
+    xorperm(Pnew, q, Px);
+    return st;
+}
+
+template <bool kGains>
+__global__ __launch_bounds__(64) void ukf_forward_q4(const KParams p) {
+    const size_t B = (size_t)p.B;
+    const size_t gl = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t t = gl >> 2;
+    const int q = (int)(gl & 3);
+    if (t >= B) return;  // whole quads leave together
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    QuadCtx cx;
+    quad_ctx_init(p.m, q, cx);
+
+    double x[4], Px[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) x[c] = p.x0[c * B + t];
+    STE_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        const int e = q * 4 + (q ^ k);
+        Px[k] = (p.flags & STE_FLAG_SHARED_P0) ? p.P0[e] : p.P0[(size_t)e * B + t];
+    }
+    auto store_row = [&](size_t row) {
+        p.fwd_mean[(row * 4 + q) * B + t] = sel4(x, q);
+        STE_UNROLL
+        for (int k = 0; k < 4; ++k) p.fwd_cov[(row * 16 + q * 4 + (q ^ k)) * B + t] = Px[k];
+    };
+    store_row(0);  // slot 0 = prior (kalman_filter.py:76-77)
+
+    int st = 0;
+    const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
+    if (kGains && initial_update && ns > 0) {
+        // smoother step 0 reads history row 0 = the prior, not the state the first predict starts from
+        double xc[4], Pc[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            xc[c] = x[c];
+            Pc[c] = Px[c];
+        }
+        QuadBasis cold;
+        cold.valid = false;
+        st |= quad_predict(p.m, cx, xc, Pc, cold, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts,
+                           p.rts_work, 0, B, t);
+    }
+    if (initial_update) {
+        double z0[4];
+        load_vec(p.z, 0, B, t, z0);
+        st |= quad_update(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+    }
+    QuadBasis basis;
+    basis.valid = false;
+    double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
+    int ui_n = -1;
+    if (ns > 0) {
+        dt_n = p.dt[t];
+        sr_n = p.sog_rate[t];
+        cr_n = p.cog_rate[t];
+        ui_n = p.upd_idx[t];
+    }
+    for (int k = 0; k < p.Nmax; ++k) {
+        const bool live = k < ns;
+        if (!__any(live)) break;
+        if (live) {
+            const double dt = dt_n, sr = sr_n, cr = cr_n;
+            const int ui = ui_n;
+            double zk[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ui >= 0) load_vec(p.z, (size_t)ui, B, t, zk);
+            if (k + 1 < ns) {
+                const size_t o = (size_t)(k + 1) * B + t;
+                dt_n = p.dt[o];
+                sr_n = p.sog_rate[o];
+                cr_n = p.cog_rate[o];
+                ui_n = p.upd_idx[o];
+            }
+            if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
+            double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
+            st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t);
+            if (ui >= 0) st |= quad_update(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
+            store_row((size_t)k + 1);
+        }
+    }
+    double chk = 0.0;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) chk += x[c] * 0.0 + Px[c] * 0.0;
+    if (!(chk == 0.0)) st |= STE_STATUS_NAN;
+    st |= dpp_move_i<0xB1>(st);
+    st |= dpp_move_i<0x4E>(st);
+    if (q == 0) p.status[t] = st;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // URTSS backward pass, one lane per track (unscented.py:285-351)
 // ---------------------------------------------------------------------------------------------------------------
@@ -822,6 +1041,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 int g_lanes_per_track = 0;
+constexpr int kDefaultLanesPerTrack = 1;
 
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -882,6 +1102,15 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
 }
 
 int launch_forward(const ste::KParams& kp, hipStream_t s) {
+    const int lanes = g_lanes_per_track ? g_lanes_per_track : kDefaultLanesPerTrack;
+    if (lanes == 4) {
+        const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
+        if (kp.rts_work)
+            hipLaunchKernelGGL(ste::ukf_forward_q4<true>, dim3(gridq), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL(ste::ukf_forward_q4<false>, dim3(gridq), dim3(64), 0, s, kp);
+        return check_hip(hipGetLastError(), "ukf_forward_q4 launch");
+    }
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
     if (kp.rts_work)
         hipLaunchKernelGGL(ste::ukf_forward_l1<true>, dim3(grid), dim3(64), 0, s, kp);
@@ -920,8 +1149,8 @@ int ste_device_count(void) {
 }
 
 int ste_set_lanes_per_track(int lanes) {
-    const int prev = g_lanes_per_track;
-    g_lanes_per_track = lanes;
+    const int prev = g_lanes_per_track ? g_lanes_per_track : kDefaultLanesPerTrack;
+    if (lanes == 0 || lanes == 1 || lanes == 4) g_lanes_per_track = lanes;
     return prev;
 }
 

@@ -19,6 +19,12 @@ constexpr double kRotTol2 = 4.930380657631324e-32;     // (2^-52)^2
 
 #define STE_UNROLL _Pragma("unroll")
 
+// Filter constants shared by every track: kernel arguments, so they sit in SGPRs / the scalar cache.
+struct Mats {
+    double fan_scale, w0, wi;
+    double H[16], Q[16], R[16];
+};
+
 // NumPy floored modulo for a positive divisor (unscented.py:250,257,340,346): fmod, then shift negatives up by b,
 // and an exact zero takes the sign of b (npy_divmod).
 __device__ __forceinline__ double floored_mod(double a, double b) {

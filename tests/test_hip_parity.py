@@ -16,6 +16,17 @@ pytestmark = pytest.mark.gpu
 MEAN_TOL = 1e-6
 COV_TOL = 1e-5
 
+@pytest.fixture(params=[1, 4], ids=["lane-per-track", "quad-per-track"], autouse=True)
+def lanes_per_track(request):
+    """Every parity test runs with both forward-kernel lane mappings (include/ste.h: ste_set_lanes_per_track)."""
+    from track_estimators._hip import binding
+
+    lib = binding.load()
+    prev = lib.ste_set_lanes_per_track(request.param)
+    yield request.param
+    lib.ste_set_lanes_per_track(prev)
+
+
 CASES = [("ukf_synthetic.npz", i) for i in range(10)] + [("ukf_edge.npz", i) for i in range(3)] + [
     ("ukf_ship_01203823.npz", i) for i in range(2)
 ]
