@@ -193,7 +193,7 @@ typedef struct ste_gp_batch_f64 {
     double* alpha;  /* [B][nout][nmax] out: K^-1 y */
     double* lml;    /* [B] out: log marginal likelihood summed over outputs */
     double* grad;   /* [B][3] out: d lml / d theta, or NULL to skip the gradient */
-    double* tr;     /* [B][3] workspace */
+    double* tr;     /* [B][3][nt] workspace, nt = (ld/64)(ld/64 + 1)/2: per-tile partial traces (summed in tile order) */
     int32_t* status; /* [B] out: 0 ok, 1 = K not positive definite */
 } ste_gp_batch_f64;
 
@@ -222,7 +222,8 @@ int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m
 
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
- *   0 = library default, 1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
+ *   0 = automatic (a quad per track up to 20 480 tracks per launch, a lane per track above),
+ *   1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
  * Returns the previous value.  Process-global; not part of the reference-facing surface.
  */
 int ste_set_lanes_per_track(int lanes);

@@ -47,7 +47,7 @@ struct GpParams {
     double* alpha;  // [B][nout][nmax]
     double* lml;    // [B]
     double* grad;   // [B][3] or null
-    double* tr;     // [B][3] workspace: tr(K^-1 Krbf), tr(K^-1 (Krbf o D2)), tr(K^-1)
+    double* tr;     // [B][3][ntiles_max] per-tile partial sums of tr(K^-1 Krbf), tr(K^-1 (Krbf o D2)), tr(K^-1)
     int32_t* status;
     int store_kinv;
 };
@@ -343,8 +343,9 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
     }
     __syncthreads();
     if (tid < 3) {
-        const double v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-        atomicAdd(&p.tr[b * 3 + tid], v);
+        // one slot per tile, summed in tile order by gp_alpha_lml: bitwise reproducible, unlike an atomic accumulation
+        const int ntiles = p.nb_max * (p.nb_max + 1) / 2;
+        p.tr[((size_t)b * 3 + tid) * ntiles + tile] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
 }
 
@@ -427,10 +428,17 @@ __global__ __launch_bounds__(256) void gp_alpha_lml(const GpParams p) {
         for (int v = 0; v < 5; ++v) r[v] = red[v][0] + red[v][1] + red[v][2] + red[v][3];
         p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
         if (p.grad) {
+            const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = nb * (nb + 1) / 2;
+            double tr[3];
+            for (int v = 0; v < 3; ++v) {
+                double acc = 0.0;
+                for (int i = 0; i < mine; ++i) acc += p.tr[((size_t)b * 3 + v) * ntiles + i];
+                tr[v] = acc;
+            }
             const double s = exp(p.theta[b * 3 + 2]);
-            p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * p.tr[b * 3 + 0]);
-            p.grad[b * 3 + 1] = 0.5 * (r[3] - nout * p.tr[b * 3 + 1]);
-            p.grad[b * 3 + 2] = 0.5 * s * (r[4] - nout * p.tr[b * 3 + 2]);
+            p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * tr[0]);
+            p.grad[b * 3 + 1] = 0.5 * (r[3] - nout * tr[1]);
+            p.grad[b * 3 + 2] = 0.5 * s * (r[4] - nout * tr[2]);
         }
     }
 }
@@ -604,8 +612,6 @@ int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
-    rc = gp_hip(hipMemsetAsync(p.tr, 0, sizeof(double) * 3 * p.B, s), "memset tr");
-    if (rc) return rc;
     hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_trtri, dim3(p.nb_max, p.B), dim3(256), 0, s, p);

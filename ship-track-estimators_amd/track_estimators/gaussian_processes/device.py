@@ -50,7 +50,8 @@ class GpDeviceBatch:
         self.t_alpha = torch.zeros((B, nout, nmax), **f64)
         self.t_lml = torch.zeros((B,), **f64)
         self.t_grad = torch.zeros((B, 3), **f64)
-        self.t_tr = torch.zeros((B, 3), **f64)
+        nbm = ld // 64
+        self.t_tr = torch.zeros((B, 3, nbm * (nbm + 1) // 2), **f64)
         self.t_status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         s = binding.SteGpBatchF64()
         s.B, s.nmax, s.nout, s.jitter = B, nmax, nout, float(jitter)

@@ -114,6 +114,7 @@ def test_fit_batch_lockstep_matches_single_fits():
         single = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
         m = single.fit(tracks[b], gpr_kwargs={"n_restarts_optimizer": 0})
         assert np.isclose(lml[b], m.log_marginal_likelihood_value_, rtol=1e-8)
-        np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-6, atol=1e-6)
+        # same objective bits in a batch and alone (deterministic reductions) -> same optimiser path
+        np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-9, atol=1e-9)
     preds = gp.predict_batch([g[f"{n}_tq"] for n in NAMES])
     assert all(p[0].shape == (len(g[f"{n}_tq"]), 2) for p, n in zip(preds, NAMES))

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 MEAN_TOL = 1e-6
 COV_TOL = 1e-5
 
-@pytest.fixture(params=[1, 4], ids=["lane-per-track", "quad-per-track"], autouse=True)
+@pytest.fixture(params=[1, 4, 0], ids=["lane-per-track", "quad-per-track", "auto"], autouse=True)
 def lanes_per_track(request):
     """Every parity test runs with both forward-kernel lane mappings (include/ste.h: ste_set_lanes_per_track)."""
     from track_estimators._hip import binding
