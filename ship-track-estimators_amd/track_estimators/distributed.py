@@ -38,3 +38,49 @@ def gather_smoothed_positions(sm_mean, group=None, out=None):
     # concatenation along dim 0 is the layout both RCCL and gloo accept for all_gather_into_tensor
     dist.all_gather_into_tensor(out.view((world * local.shape[0],) + tuple(local.shape[1:])), local, group=group)
     return out
+
+
+class OverlappedGather:
+    """
+    Double-buffered, asynchronous form of ``gather_smoothed_positions`` for a stream of batches.
+
+    ``launch(sm_mean)`` snapshots the lon/lat rows into a send buffer on the current stream and starts the all-gather
+    with ``async_op=True``: RCCL runs it on its own stream behind the kernels already queued, while the caller goes on
+    to queue the next batch's filter kernels.  Two slots alternate; a slot is waited for just before it is reused, and
+    ``finish()`` drains what is still in flight.  ``result(i)`` is the gathered tensor of the i-th launch (valid after
+    that launch was waited for).
+    """
+
+    def __init__(self, nrows: int, ntracks: int, device, dtype=None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        dtype = dtype or torch.float64
+        self.send = [torch.empty((nrows, 2, ntracks), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [torch.empty((self.world, nrows, 2, ntracks), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.count = 0
+
+    def launch(self, sm_mean):
+        slot = self.count & 1
+        if self.work[slot] is not None:
+            self.work[slot].wait()  # the current stream now waits for the collective that last used this slot
+        self.send[slot].copy_(sm_mean[:, :2, :])
+        out = self.recv[slot]
+        self.work[slot] = self.dist.all_gather_into_tensor(
+            out.view((self.world * out.shape[1],) + tuple(out.shape[2:])), self.send[slot], group=self.group,
+            async_op=True)
+        self.count += 1
+        return slot
+
+    def finish(self):
+        for slot in (0, 1):
+            if self.work[slot] is not None:
+                self.work[slot].wait()
+                self.work[slot] = None
+
+    def result(self, slot: int):
+        return self.recv[slot]

@@ -44,6 +44,11 @@ def _worker(rank, world, port, total, q):
         hb = batch.pack_uniform(sb, 2, H, Q, R, P0)
         local = torch.from_numpy(_fake_smoothed(hb))
         g = distributed.gather_smoothed_positions(local)
+        # the overlapped, double-buffered form must deliver the same tensors for a stream of three batches
+        og = distributed.OverlappedGather(local.shape[0], local.shape[2], "cpu")
+        slots = [og.launch(local + float(i)) for i in range(3)]
+        og.finish()
+        assert torch.equal(og.result(slots[2]), g + 2.0) and torch.equal(og.result(slots[1]), g + 1.0)
         q.put((rank, lo, hi, g.numpy()))
         dist.barrier()
     finally:
