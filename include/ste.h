@@ -51,11 +51,14 @@ extern "C" {
 /* ste_ukf_batch_f64.flags */
 #define STE_FLAG_SHARED_P0 0x1u        /* P0 is one 4x4 matrix [16] shared by all tracks (else [16][B]) */
 #define STE_FLAG_NO_INITIAL_UPDATE 0x2u /* skip the update with z[:,0] that run() performs before the first predict */
+#define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
+                                the reference ships with its call site commented out, :228) */
 
 /* status[] bits (per track) */
 #define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
 #define STE_STATUS_CLAMPED 0x2    /* sigma fan: negative eigenvalue clamped to 0 (sqrtm went complex in the reference) */
 #define STE_STATUS_NOCONV 0x4     /* Jacobi eigen-solve hit its sweep cap */
+#define STE_STATUS_ROBUST_CAP 0x8 /* robust update: criterion still above chi_alpha after robust_max_iter rescalings */
 
 /*
  * One batch of B independent tracks, padded to Nmax filter steps and Tmax observations.
@@ -114,6 +117,11 @@ typedef struct ste_ukf_batch_f64 {
      * fwd_mean / fwd_cov (required when the forward history was not produced by ste_ukf_forward_f64 on this batch).
      */
     double* rts_work;
+
+    /* robust update (STE_FLAG_ROBUST): threshold chi_alpha (the reference hard-codes 50) and iteration cap (0 = 50) */
+    double chi_alpha;
+    int32_t robust_max_iter;
+    int32_t reserved2;
 } ste_ukf_batch_f64;
 
 int ste_version(void);
@@ -154,6 +162,14 @@ int ste_ukf_predict_f64(int64_t count, const double* x, const double* P, const d
  */
 int ste_ukf_update_f64(int64_t count, const double* x, const double* P, const double* z, const double* noise,
                        const double* H, const double* R, double* x_out, double* P_out, int32_t* status, void* stream);
+
+/*
+ * Terms of the robustification helpers for `count` independent (x, P, z) triples, with y = z - x as the reference
+ * writes it: gamma = |y^T (H P H^T + R)^+ y| (criterion_index, unscented.py:389-428) and
+ * denom = y^T S^+ R S^+ y (update_lambda_factor, :468-478).  H, R: HOST 4x4.
+ */
+int ste_ukf_robust_terms_f64(int64_t count, const double* x, const double* P, const double* z, const double* H,
+                             const double* R, double* gamma, double* denom, void* stream);
 
 /*
  * Sigma fans of `count` (x, P) pairs: out[j][c][i] for sigma point j in 0..8, component c, pair i.

@@ -280,6 +280,45 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
     return st;
 }
 
+// Chang (2014) Mahalanobis terms of the robustification helpers (unscented.py:389-483), with the reference's y = z - x:
+//   gamma = | y^T (H P H^T + R)^+ y |          criterion_index, :420-426
+//   denom =   y^T (S^+ R S^+) y                  denominator of update_lambda_factor, :468-478
+__device__ __forceinline__ int robust_terms(const double (&H)[4][4], const double (&R)[4][4], const double (&x)[4],
+                                            const double (&P)[4][4], const double (&z)[4], double& gamma,
+                                            double& denom) {
+    double HP[4][4], S[4][4], Si[4][4], y[4], u[4], v[4];
+    mm(H, P, HP);
+    mmt(HP, H, S);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        y[r] = z[r] - x[r];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) S[r][c] += R[r][c];
+    }
+    const int st = sym_pinv4(S, Si);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        double acc = 0.0;
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) acc = fma(Si[r][c], y[c], acc);
+        u[r] = acc;  // S^+ y
+    }
+    double g = 0.0, d = 0.0;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        g = fma(y[r], u[r], g);
+        double acc = 0.0;
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) acc = fma(R[r][c], u[c], acc);
+        v[r] = acc;  // R S^+ y
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) d = fma(u[r], v[r], d);  // (S^+ y)^T R (S^+ y) = y^T S^+ R S^+ y  (S^+ symmetric)
+    gamma = fabs(g);
+    denom = d;
+    return st;
+}
+
 // Linear Kalman update with pseudo-inverse gain and Joseph-form covariance (unscented.py:219-265).
 __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double (&P)[4][4], const double (&zin)[4],
                                           const double* noise, size_t nrow, size_t B, size_t t) {
@@ -295,6 +334,23 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
     double z[4];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) z[c] = zin[c];
+    int rst = 0;
+    if (p.robust_iters > 0) {
+        // Opt-in robustification (check_robustness, unscented.py:353-387) on the un-noised observation: while the
+        // criterion exceeds chi_alpha, lambda += (gamma - chi)/denom and R <- lambda R (compounding, as written there).
+        double gamma, denom, lambda = 1.0;
+        rst |= robust_terms(H, R, x, P, z, gamma, denom);
+        for (int it = 0; it < p.robust_iters && gamma > p.chi_alpha; ++it) {
+            lambda += (gamma - p.chi_alpha) / denom;
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) R[r][c] *= lambda;
+            }
+            rst |= robust_terms(H, R, x, P, z, gamma, denom);
+        }
+        if (gamma > p.chi_alpha) rst |= 0x8;
+    }
     if (noise) {
         STE_UNROLL
         for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
@@ -307,7 +363,7 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
         STE_UNROLL
         for (int c = 0; c < 4; ++c) S[r][c] += R[r][c];
     }
-    const int st = sym_pinv4(S, Si);
+    const int st = sym_pinv4(S, Si) | rst;
     mmt(P, H, PHt);
     mm(PHt, Si, K);
     double y[4];
@@ -1118,6 +1174,29 @@ __global__ __launch_bounds__(64) void update_kernel(size_t count, const Mats m, 
     if (status) status[i] = st;
 }
 
+// Robustification terms for `count` independent (x, P, z) triples (criterion_index / update_lambda_factor).
+__global__ __launch_bounds__(64) void robust_terms_kernel(size_t count, const Mats m, const double* x, const double* P,
+                                                          const double* z, double* gamma, double* denom) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    double H[4][4], R[4][4], xi[4], Pi[4][4], zi[4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            H[r][c] = m.H[r * 4 + c];
+            R[r][c] = m.R[r * 4 + c];
+        }
+    }
+    load_vec(x, 0, count, i, xi);
+    load_mat(P, 0, count, i, Pi);
+    load_vec(z, 0, count, i, zi);
+    double g, d;
+    robust_terms(H, R, xi, Pi, zi, g, d);
+    gamma[i] = g;
+    denom[i] = d;
+}
+
 }  // namespace ste
 
 // ===============================================================================================================
@@ -1132,7 +1211,8 @@ int g_lanes_per_track = 0;  // 0 = automatic
 // 10 000 and 40 000 tracks: 5.3 vs 3.1 ms at 10 000, 5.8 vs 9.5 ms at 40 000) the lane-per-track kernels win because
 // they waste no lanes on replicated work.
 constexpr int kQuadMaxTracks = 20480;
-int choose_lanes(int B) {
+int choose_lanes(int B, bool robust) {
+    if (robust) return 1;  // the robust update exists in the lane-per-track kernels only
     if (g_lanes_per_track == 1 || g_lanes_per_track == 4) return g_lanes_per_track;
     return B <= kQuadMaxTracks ? 4 : 1;
 }
@@ -1172,6 +1252,8 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     memcpy(kp->m.H, b->H, sizeof(double) * 16);
     memcpy(kp->m.Q, b->Q, sizeof(double) * 16);
     memcpy(kp->m.R, b->R, sizeof(double) * 16);
+    kp->m.chi_alpha = b->chi_alpha;
+    kp->m.robust_iters = (b->flags & STE_FLAG_ROBUST) ? (b->robust_max_iter > 0 ? b->robust_max_iter : 50) : 0;
     kp->nsteps = b->nsteps;
     kp->x0 = b->x0;
     kp->P0 = b->P0;
@@ -1196,7 +1278,7 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
 }
 
 int launch_forward(const ste::KParams& kp, hipStream_t s) {
-    if (choose_lanes(kp.B) == 4) {
+    if (choose_lanes(kp.B, kp.m.robust_iters > 0) == 4) {
         const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
         if (kp.rts_work)
             hipLaunchKernelGGL(ste::ukf_forward_q4<true>, dim3(gridq), dim3(64), 0, s, kp);
@@ -1221,7 +1303,7 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
             int rc = check_hip(hipGetLastError(), "urtss_gain launch");
             if (rc) return rc;
         }
-        if (choose_lanes(kp.B) == 4) {
+        if (choose_lanes(kp.B, false) == 4) {
             const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
             hipLaunchKernelGGL(ste::urtss_combine_q4, dim3(gridq), dim3(64), 0, s, kp);
         } else {
@@ -1317,6 +1399,21 @@ int ste_ukf_update_f64(int64_t count, const double* x, const double* P, const do
     hipLaunchKernelGGL(ste::update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, m, x, P, z,
                        noise, x_out, P_out, status);
     return check_hip(hipGetLastError(), "ukf_update launch");
+}
+
+int ste_ukf_robust_terms_f64(int64_t count, const double* x, const double* P, const double* z, const double* H,
+                             const double* R, double* gamma, double* denom, void* stream) {
+    if (count < 0) return fail(STE_EINVAL, "count must be >= 0");
+    if (count == 0) return STE_OK;
+    if (!x || !P || !z || !H || !R || !gamma || !denom) return fail(STE_EINVAL, "NULL pointer argument");
+    ste::Mats m;
+    memset(&m, 0, sizeof(m));
+    memcpy(m.H, H, sizeof(double) * 16);
+    memcpy(m.R, R, sizeof(double) * 16);
+    const unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL(ste::robust_terms_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, (size_t)count, m, x, P, z,
+                       gamma, denom);
+    return check_hip(hipGetLastError(), "robust_terms launch");
 }
 
 int ste_sigma_points_f64(int64_t count, const double* x, const double* P, double scale, double* out, void* stream) {

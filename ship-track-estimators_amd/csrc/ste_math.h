@@ -23,6 +23,8 @@ constexpr double kRotTol2 = 4.930380657631324e-32;     // (2^-52)^2
 struct Mats {
     double fan_scale, w0, wi;
     double H[16], Q[16], R[16];
+    double chi_alpha;  // robust update threshold (unscented.py:357: 50)
+    int robust_iters;  // 0 = robustification off (the reference's call site is commented out, unscented.py:228)
 };
 
 // NumPy floored modulo for a positive divisor (unscented.py:250,257,340,346): fmod, then shift negatives up by b,

@@ -16,10 +16,12 @@ LIB_PATH = os.environ.get("STE_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libs
 
 STE_FLAG_SHARED_P0 = 0x1
 STE_FLAG_NO_INITIAL_UPDATE = 0x2
+STE_FLAG_ROBUST = 0x4
 
 STE_STATUS_NAN = 0x1
 STE_STATUS_CLAMPED = 0x2
 STE_STATUS_NOCONV = 0x4
+STE_STATUS_ROBUST_CAP = 0x8
 
 _dp = C.c_void_p  # device / host pointers travel as integers
 
@@ -59,6 +61,9 @@ class SteUkfBatchF64(C.Structure):
         ("sm_cov", _dp),
         ("status", _dp),
         ("rts_work", _dp),
+        ("chi_alpha", C.c_double),
+        ("robust_max_iter", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -99,6 +104,7 @@ SYMBOLS = {
     "ste_ukf_predict_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
                                       _dp, _dp, _dp, C.c_void_p]),
     "ste_ukf_update_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
+    "ste_ukf_robust_terms_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_sigma_points_f64": (C.c_int, [C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
     "ste_sigma_points_generic_f64": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
     "ste_gp_last_error": (C.c_char_p, []),

@@ -63,6 +63,26 @@ def rts_rate_index(nrows: int, dts_len: int, T: int) -> np.ndarray:
     return idx[: nrows - 1]
 
 
+def draw_reference_noise(Q, R, dt, dts, t0=0):
+    """
+    Noise arrays for one track drawn from NumPy's global generator with the reference's calls in the reference's order
+    (unscented.py:198,232,320): initial update, then per step the predict draw (+ an update draw when the trigger
+    fires), then the smoother's draws for k = N-1 ... 0.  Returns the dict ``pack_tracks(noise=[...])`` expects.
+    """
+    N = len(dt)
+    upd_idx, _, _ = update_schedule(dt, dts, t0)
+    sq, sr = np.sqrt(np.diag(Q)), np.sqrt(np.diag(R))
+    npred, nupd, nrts = np.zeros((N, 4)), np.zeros((N + 1, 4)), np.zeros((N, 4))
+    nupd[0] = np.random.normal(scale=sr, size=(4))
+    for k in range(N):
+        npred[k] = np.random.normal(scale=sq, size=(4))
+        if upd_idx[k] >= 0:
+            nupd[k + 1] = np.random.normal(scale=sr, size=(4))
+    for k in range(N - 1, -1, -1):
+        nrts[k] = np.random.normal(scale=sq, size=(4))
+    return dict(noise_pred=npred, noise_upd=nupd, noise_rts=nrts)
+
+
 @dataclasses.dataclass
 class HostBatch:
     """NumPy image of ``struct ste_ukf_batch_f64``; arrays are C-contiguous with the track index last."""
@@ -88,6 +108,9 @@ class HostBatch:
     noise_rts: Optional[np.ndarray] = None  # (Nmax, 4, B)
     weights_computed: bool = True
     initial_update: bool = True
+    robust: bool = False  # opt-in Mahalanobis robust update (not on the reference's shipped path)
+    chi_alpha: float = 50.0
+    host_status: Optional[np.ndarray] = None  # (B,) int32 bits set while packing (STATUS_HOST_INDEX)
 
     @property
     def shared_p0(self) -> bool:
@@ -106,13 +129,20 @@ def _as44(M, name):
     return M
 
 
+STATUS_HOST_INDEX = 0x10  # the reference would raise IndexError for this track (update index past the last observation)
+
+
 def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, R, P0, t0s=None,
-                noise: Optional[Sequence[dict]] = None) -> HostBatch:
+                noise: Optional[Sequence[dict]] = None, on_error: str = "flag") -> HostBatch:
     """
     Pack B tracks (objects carrying ``z`` (4,T), ``dts`` (T-1,), ``sog_rate`` (T,), ``cog_rate`` (T,) like a
     reference ``ShipTrack``, ship_track.py:70-83) with their per-track ``dt`` arrays and priors into a HostBatch.
     Ragged batches are padded to the longest track.  ``P0`` is one 4x4 shared matrix or a sequence of B matrices.
     ``noise`` (test-only) is a per-track list of dicts with ``noise_pred`` (N,4), ``noise_upd`` (N+1,4), ``noise_rts`` (N,4).
+    ``on_error``: a track whose update index runs past its last observation (duplicate timestamps make the
+    float-equality trigger fire twice per gap) raises IndexError in the reference (kalman_filter.py:105).  "raise" does
+    the same; "flag" (default, the batch example's try/except/continue) truncates that track at the offending step and
+    sets STATUS_HOST_INDEX in ``host_status``.
     """
     B = len(tracks)
     if B == 0:
@@ -122,6 +152,7 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
     Ts = [np.asarray(tr.z).shape[1] for tr in tracks]
     Nmax, Tmax = max(Ns), max(Ts)
     nsteps = np.asarray(Ns, dtype=np.int32)
+    host_status = np.zeros(B, dtype=np.int32)
     x0 = np.zeros((4, B))
     dt = np.zeros((Nmax, B))
     sr = np.zeros((Nmax, B))
@@ -153,14 +184,21 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
         cog_rate = np.asarray(tr.cog_rate, dtype=np.float64)
         u, ridx, _ = update_schedule(d, dts, 0 if t0s is None else t0s[b])
         if N and (u.max() >= T or ridx.max() >= len(sog_rate)):
-            raise IndexError("update index runs past the last observation (kalman_filter.py:105)")
+            if on_error == "raise":
+                raise IndexError("update index runs past the last observation (kalman_filter.py:105)")
+            bad = np.flatnonzero((u >= T) | (ridx >= len(sog_rate)))[0]
+            N = int(bad)
+            Ns[b] = N
+            nsteps[b] = N
+            host_status[b] |= STATUS_HOST_INDEX
+            d, u, ridx = d[:N], u[:N], ridx[:N]
         x0[:, b] = np.asarray(x0s[b], dtype=np.float64).reshape(-1)
         z[:T, :, b] = zb.T
         dt[:N, b] = d
         ui[:N, b] = u
         sr[:N, b] = sog_rate[ridx]
         cr[:N, b] = cog_rate[ridx]
-        if N and len(dts):
+        if N and len(dts) and not host_status[b]:
             try:
                 rr = rts_rate_index(N + 1, len(dts), len(sog_rate))
                 srr[:N, b] = sog_rate[rr]
@@ -177,7 +215,7 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
     same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
     return HostBatch(B=B, Nmax=Nmax, Tmax=Tmax, H=H, Q=Q, R=R, nsteps=nsteps, x0=x0, P0=P0p, dt=dt, sog_rate=sr,
                      cog_rate=cr, sog_rate_rts=None if same_rts else srr, cog_rate_rts=None if same_rts else crr,
-                     upd_idx=ui, z=z, noise_pred=npred, noise_upd=nupd, noise_rts=nrts)
+                     upd_idx=ui, z=z, noise_pred=npred, noise_upd=nupd, noise_rts=nrts, host_status=host_status)
 
 
 def pack_uniform(sb, substeps: int, H, Q, R, P0) -> HostBatch:
@@ -253,7 +291,9 @@ class DeviceBatch:
         s = binding.SteUkfBatchF64()
         s.B, s.Nmax, s.Tmax, s.n = B, N, hb.Tmax, 4
         s.flags = (binding.STE_FLAG_SHARED_P0 if hb.shared_p0 else 0) | (
-            0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE)
+            0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE) | (
+            binding.STE_FLAG_ROBUST if hb.robust else 0)
+        s.chi_alpha, s.robust_max_iter = float(hb.chi_alpha), 50
         s.fan_scale, s.w0, s.wi = fan_scale, w0, wi
         s.H, s.Q, s.R = hb.H.ctypes.data, hb.Q.ctypes.data, hb.R.ctypes.data
         for name in self._IN:
@@ -303,13 +343,15 @@ def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: b
     """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays."""
     db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains)
     if smooth:
-        if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts).any():
+        if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts[:, (hb.host_status == 0) if hb.host_status is not None else slice(None)]).any():
             raise IndexError("smoother rate expansion too short for at least one track (unscented.py:287-292,310)")
         db.run()
     else:
         db.forward()
     db.torch.cuda.synchronize(db.device)
     out = {"status": db.status_host(), "nsteps": hb.nsteps.copy()}
+    if hb.host_status is not None:
+        out["status"] = out["status"] | hb.host_status
     out["means"], out["covs"] = db.filtered()
     if smooth:
         out["means_smoothed"], out["covs_smoothed"] = db.smoothed()

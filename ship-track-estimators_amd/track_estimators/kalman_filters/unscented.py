@@ -207,9 +207,13 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         trk = types.SimpleNamespace(z=z, dts=ship_track.dts, sog_rate=ship_track.sog_rate, cog_rate=ship_track.cog_rate)
         hb = _batch.pack_tracks([trk], [dt], [np.asarray(self.x, dtype=np.float64).reshape(-1)], self.H, self.Q, self.R,
                                 np.asarray(self.P, dtype=np.float64), t0s=[self.time],
-                                noise=[dict(noise_pred=npred, noise_upd=nupd, noise_rts=np.zeros((N, 4)))])
+                                noise=[dict(noise_pred=npred, noise_upd=nupd, noise_rts=np.zeros((N, 4)))],
+                                on_error="raise")
         out = _batch.run_batch(hb, smooth=False)
         self._status = int(out["status"][0])
+        if self._status & 0x1:
+            # the reference dies inside np.linalg.pinv once a NaN/inf reaches the covariance (e.g. dt = 0 -> sog = inf)
+            raise np.linalg.LinAlgError("SVD did not converge")
         return out["means"][0], out["covs"][0], upd_idx, t_end
 
     def rts_step(self, fwd_means, fwd_vars, ship_track: ShipTrack, *args, **kwargs):
@@ -257,10 +261,58 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         torch.cuda.synchronize(dev)
         sm, sP = db.smoothed()
         self._status_smoother = int(db.status_host()[0])
+        if self._status_smoother & 0x1:
+            raise np.linalg.LinAlgError("SVD did not converge")
         return sm[0].reshape(nrows, 4, 1), sP[0]
 
     # -- robustification helpers (unscented.py:353-511) -------------------------------------------------------------
-    # The reference's call site is commented out (unscented.py:228); they are not on the filter path.
-    def check_robustness(self, z, P, R):
-        raise NotImplementedError("Mahalanobis robustification is not on the reference's filter path (call site "
-                                  "commented out at unscented.py:228) and has no device implementation yet")
+    # The reference's call site is commented out (unscented.py:228), so ``run`` never invokes these; they are kept as
+    # callable methods with the reference's signatures.  The batched path offers the same loop as an opt-in flag
+    # (``HostBatch.robust``), evaluated inside the update kernel.
+    def _robust_terms(self, z, P, R):
+        """(gamma, denom) of unscented.py:420-426 and :468-478 for this filter's x and H, computed on the GPU."""
+        from .._hip import binding
+
+        self._require_dim4("robustification")
+        lib = binding.require_gpu()
+        torch, dev = _dev()
+        x, Pm = _up(torch, dev, self.x, (4, 1)), _up(torch, dev, P, (16, 1))
+        zt = _up(torch, dev, np.asarray(z, dtype=np.float64).reshape(-1), (4, 1))
+        H, Rm = _batch._as44(self.H, "H"), _batch._as44(R, "R")
+        g, d = torch.empty((1,), dtype=torch.float64, device=dev), torch.empty((1,), dtype=torch.float64, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        binding.check(lib.ste_ukf_robust_terms_f64(1, x.data_ptr(), Pm.data_ptr(), zt.data_ptr(), H.ctypes.data,
+                                                   Rm.ctypes.data, g.data_ptr(), d.data_ptr(), stream),
+                      "ste_ukf_robust_terms_f64")
+        return float(g.item()), float(d.item())
+
+    def criterion_index(self, z: np.ndarray, P: np.ndarray, R: np.ndarray) -> float:
+        """Mahalanobis judging index ``|y^T (H P H^T + R)^+ y|`` with ``y = z - x`` (unscented.py:389-428)."""
+        return self._robust_terms(z, P, R)[0]
+
+    def update_lambda_factor(self, lambda_factor: float, criterion_index: float, chi_alpha: float, z: np.ndarray,
+                             P: np.ndarray, R: np.ndarray) -> float:
+        """``lambda + (criterion - chi_alpha) / (y^T S^+ R S^+ y)`` (unscented.py:430-483)."""
+        _, denom = self._robust_terms(z, P, R)
+        return float(lambda_factor + (criterion_index - chi_alpha) / denom)
+
+    def scale_measurement_uncertainty(self, R: np.ndarray, lambda_factor: float) -> np.ndarray:
+        """``R * lambda`` (unscented.py:485-511)."""
+        return R * lambda_factor
+
+    def check_robustness(self, z: np.ndarray, P: np.ndarray, R: np.ndarray) -> np.ndarray:
+        """The reference's rescaling loop (unscented.py:353-387), including its fresh noise draw per iteration and its
+        prints; returns the scaled R."""
+        lambda_factor = 1
+        chi_alpha = 50
+        z = np.asarray(z, dtype=np.float64).reshape(-1, 1)
+        zn = z + self._draw(R).reshape(-1, 1)
+        judging_index = self.criterion_index(zn, P, R)
+        print(judging_index, lambda_factor)
+        while judging_index > chi_alpha:
+            zn = z + self._draw(R).reshape(-1, 1)
+            lambda_factor = self.update_lambda_factor(lambda_factor, judging_index, chi_alpha, zn, P, R)
+            R = self.scale_measurement_uncertainty(R, lambda_factor)
+            judging_index = self.criterion_index(zn, P, R)
+            print(judging_index, lambda_factor)
+        return R

@@ -302,6 +302,40 @@ def gp_cases():
     return out
 
 
+def modern_cases():
+    """BASELINE configs[3]: data/modern_ships, all 7 ids, 2 sub-steps, haversine sog/cog, zero noise.  Two ships run
+    clean (N = 16 794 and 17 084 steps); five contain duplicate timestamps (dt = 0 -> sog = dist/0) and the reference
+    dies with ``LinAlgError: SVD did not converge`` inside pinv -- recorded as such.  Histories are sampled (every 50th
+    row + the last 20) to keep the fixture small."""
+    csv = "/root/reference/data/modern_ships/modern_ship_data.csv"
+    H = np.diag([1, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6]); P = np.eye(4)
+    out = {}
+    ids = ["AMOUK05", "WDG7520", "WCE5063", "WDA7827", "WGAE", "KAOU", "SJA4RSK"]
+    for sid in ids:
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.read_csv(csv, ship_id=sid, id_col="id", lat_col="lat", lon_col="lon")
+        st.get_measurements(include_sog=True, include_cog=True)
+        st.calculate_cog_rate()
+        st.calculate_sog_rate()
+        out[f"{sid}_T"] = np.int64(len(st.lon))
+        out[f"{sid}_zero_dt"] = np.int64((st.dts == 0).sum())
+        out[f"{sid}_zsum"] = np.array([np.nansum(np.where(np.isfinite(st.z), st.z, 0.0)), st.dts.sum()])
+        try:
+            res = run_reference(copy.deepcopy(st), H, Q, R, P, 2, "zero")
+            N = len(res["dt"])
+            rows = np.unique(np.concatenate([np.arange(0, N + 1, 50), np.arange(N - 19, N + 1)]))
+            out[f"{sid}_ok"] = np.int64(1)
+            out[f"{sid}_rows"] = rows
+            for k in ("means", "covs", "means_smoothed", "covs_smoothed"):
+                out[f"{sid}_{k}"] = res[k][rows]
+            print(f"modern {sid}: N={N} ok")
+        except np.linalg.LinAlgError as e:
+            out[f"{sid}_ok"] = np.int64(0)
+            print(f"modern {sid}: LinAlgError {e}")
+    out["ids"] = np.array(ids)
+    return out
+
+
 def csv_fixture():
     """Rows of ship 01203823 cut from the reference's data file (the input of its own CLI example), plus one of the
     header rows the source file repeats between ships, so the id column stays a string column as in the full file."""
@@ -381,6 +415,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats())
     csv_fixture()
     np.savez_compressed(os.path.join(HERE, "gp.npz"), **gp_cases())
+    np.savez_compressed(os.path.join(HERE, "modern_ships.npz"), **modern_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|double)\s*\*?\s*(\w+)\s*;", body)
         assert fields == [f[0] for f in mirror._fields_], cname
-    assert C.sizeof(binding.SteUkfBatchF64) == 24 + 3 * 8 + 22 * 8
+    assert C.sizeof(binding.SteUkfBatchF64) == 24 + 3 * 8 + 22 * 8 + 16
 
 
 def test_argument_validation_without_gpu():

@@ -1,0 +1,187 @@
+"""CLI surface (reference cli/main_cli.py), the robustification helpers, and BASELINE configs[3] (modern ships)."""
+import gzip
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+from conftest import GOLDEN
+
+
+def test_input_settings_parsing():
+    from track_estimators.cli.main_cli import _get_input_matrix, get_input_settings
+
+    s = {"dim": 4, "H": [1, 1, 0, 0], "R": [0.001, 0.001, 0, 0], "Q": [1e-2, 1e-2, 1e-4, 1e-4], "P": [1.0, 1, 1, 1],
+         "dt": -1, "nsteps": 2}
+    dim, dt, nsteps, H, Q, R, P, smooth = get_input_settings(s)
+    assert (dim, dt, nsteps, smooth) == (4, -1, 2, None)
+    assert np.array_equal(H, np.diag([1, 1, 0, 0])) and np.array_equal(Q, np.diag([1e-2, 1e-2, 1e-4, 1e-4]))
+    assert get_input_settings({**s, "smooth": 5})[-1] == 5
+    full = np.arange(16.0).reshape(4, 4).tolist()
+    assert np.array_equal(_get_input_matrix({"H": full}, "H", 4), np.arange(16.0).reshape(4, 4))
+    for missing in ("dim", "dt", "nsteps", "H", "Q", "R", "P"):
+        with pytest.raises(KeyError):
+            get_input_settings({k: v for k, v in s.items() if k != missing})
+    with pytest.raises(AssertionError):
+        _get_input_matrix({"H": [1, 1, 0]}, "H", 4)
+
+
+def test_parser_flags_match_reference_surface():
+    from track_estimators.cli.argument_parser import create_parser
+
+    a = create_parser().parse_args(["-t", "f.csv", "-s", "01203823", "-ic", "primary.id", "-lat", "lat", "-lon", "lon",
+                                    "-rts", "-rev", "-o", "out", "-i", "in.json"])
+    assert (a.track_file, a.ship_id, a.id_col, a.lat_id, a.lon_id) == ("f.csv", "01203823", "primary.id", "lat", "lon")
+    assert a.apply_rts_smoother and a.reverse and a.output_prefix == "out" and a.input_file == "in.json"
+    d = create_parser().parse_args(["-t", "f", "-s", "1", "-ic", "i", "-lat", "a", "-lon", "o"])
+    assert d.input_file == "input.json" and d.output_prefix == "output" and not d.apply_rts_smoother and not d.reverse
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path, monkeypatch):
+    """The reference's CLI example (examples/cli_example/run.sh + input.json) through this package's entry point.
+    Row 0 of the predictions and the dts file are noise-free known answers of the reference's committed outputs."""
+    from track_estimators.cli.main_cli import track_estimator
+
+    monkeypatch.chdir(tmp_path)
+    with open("input.json", "w") as f:
+        json.dump({"dim": 4, "H": [1, 1, 0, 0], "R": [0.001, 0.001, 0, 0], "Q": [1e-2, 1e-2, 1e-4, 1e-4],
+                   "P": [1.0, 1.0, 1.0, 1.0], "dt": -1, "nsteps": 2}, f)
+    csv = os.path.join(GOLDEN, "ship_01203823.csv")
+    track_estimator(["-i", "input.json", "-o", "output", "-t", csv, "-s", "01203823", "-ic", "primary.id", "-lat", "lat",
+                     "-lon", "lon", "-rts", "--no-noise"])
+    pred = np.loadtxt("output_01203823_predictions.txt")
+    var = np.loadtxt("output_01203823_variances.txt")
+    dts = np.loadtxt("output_01203823_dts.txt")
+    orig = np.loadtxt("original_01203823_track.txt")
+    sm = np.loadtxt("output_01203823_predictions_smoothed.txt")
+    vsm = np.loadtxt("output_01203823_variances_smoothed.txt")
+    assert pred.shape == (103, 4) and var.shape == (103, 4) and sm.shape == (103, 4) and vsm.shape == (103, 4)
+    assert dts.shape == (102,) and orig.shape == (52, 2)
+    np.testing.assert_allclose(pred[0], [-30.5, -0.5, 14.578418614021368, 198.52495095065817], rtol=1e-11)
+    assert set(np.unique(dts)) <= {11.5, 12.0, 12.5}
+    assert np.array_equal(var[0], [1.0, 1.0, 1.0, 1.0]) and np.all(np.isfinite(sm))
+    # same answer as the class API on the same inputs
+    from track_estimators.kalman_filters.non_linear_process import geodetic_dynamics
+    from track_estimators.kalman_filters.unscented import UnscentedKalmanFilter
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import generate_dts
+
+    st = ShipTrack()
+    st.read_csv(csv, ship_id="01203823", id_col="primary.id")
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    ukf = UnscentedKalmanFilter(H=np.diag([1, 1, 0, 0]), Q=np.diag([1e-2, 1e-2, 1e-4, 1e-4]), R=np.diag([0.001, 0.001, 0, 0]),
+                                P=np.eye(4), x0=z[:, 0].reshape(-1, 1).copy(), non_linear_process=geodetic_dynamics)
+    ukf.inject_noise = False
+    dt = generate_dts(st.dts, 2)
+    m, _ = ukf.run(len(dt), dt, st)
+    np.testing.assert_allclose(pred, m, rtol=1e-12, atol=1e-12)
+    # batch mode: two ids in one launch write the same files per id
+    os.makedirs("b", exist_ok=True)
+    monkeypatch.chdir(tmp_path / "b")
+    shutil.copy(tmp_path / "input.json", "input.json")
+    hist = os.path.join(GOLDEN, "data", "historical_ship_data.csv.gz")
+    with gzip.open(hist, "rb") as src, open("hist.csv", "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    track_estimator(["-t", "hist.csv", "-s", "01203823,01205638", "-ic", "primary.id", "-lat", "lat", "-lon", "lon", "-rts",
+                     "--no-noise"])
+    pb = np.loadtxt("output_01203823_predictions.txt")
+    np.testing.assert_allclose(pb, pred, rtol=1e-12, atol=1e-12)
+    assert os.path.exists("output_01205638_predictions_smoothed.txt")
+
+
+@pytest.mark.gpu
+def test_robust_helpers_and_flag():
+    """criterion_index / update_lambda_factor methods vs the reference's known answers; the opt-in robust update of the
+    batched path vs the oracle's restatement of check_robustness (noise-free)."""
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+    from track_estimators.kalman_filters.unscented import UnscentedKalmanFilter
+
+    k = np.load(os.path.join(GOLDEN, "kats.npz"))
+    for i in range(8):
+        u = UnscentedKalmanFilter(H=k["H"], Q=k["Q"], R=k["R"], P=k["rb_P"][i], x0=k["rb_x"][i])
+        c = u.criterion_index(k["rb_z"][i].reshape(-1, 1), k["rb_P"][i], k["R"])
+        assert np.isclose(c, k["rb_ci"][i], rtol=1e-10)
+        lam = u.update_lambda_factor(1.0, c, 50.0, k["rb_z"][i].reshape(-1, 1), k["rb_P"][i], k["R"])
+        assert np.isclose(lam, k["rb_lambda"][i], rtol=1e-10)
+        assert np.array_equal(u.scale_measurement_uncertainty(k["R"], 3.0), k["R"] * 3.0)
+    # robust flag: a track with one gross outlier; emulate with the oracle step by step
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(3, nobs=9, gap_h=1.0, seed0=31)
+    sb.z[1, 0, 4] += 25.0  # 25 degrees of longitude off
+    hb = batch.pack_uniform(sb, 1, H, Q, R, P0)
+    hb.robust = True
+    out = batch.run_batch(hb, smooth=False)
+    plain = batch.run_batch(batch.pack_uniform(sb, 1, H, Q, R, P0), smooth=False)
+    # oracle emulation for track 1
+    W = orc.weight_matrix(4)
+    x, P = sb.z[1][:, 0].reshape(-1, 1).copy(), P0.copy()
+
+    def upd(x, P, z):
+        Rr = orc.check_robustness(x, H, z, P, R)
+        return orc.update_track(x, P, H, Rr, z)
+
+    x, P = upd(x, P, sb.z[1][:, 0])
+    for kk in range(8):
+        x, P = orc.predict_track(x, P, Q, W, sb.dts[1][kk], sb.sog_rate[1][kk], sb.cog_rate[1][kk])
+        x, P = upd(x, P, sb.z[1][:, kk + 1])
+        np.testing.assert_allclose(out["means"][1, kk + 1], x[:, 0], rtol=1e-7, atol=1e-9)
+    assert abs(out["means"][1, 4, 0] - plain["means"][1, 4, 0]) > 1.0  # the outlier was down-weighted
+    np.testing.assert_allclose(out["means"][0], plain["means"][0], rtol=1e-9)  # clean tracks are untouched
+
+
+@pytest.mark.gpu
+def test_config4_modern_ships_batch():
+    """All seven ids of data/modern_ships in one ragged batch (13 274 .. 19 236 steps).  Two ships run clean and must
+    match the reference; five contain duplicate timestamps (dt = 0): the reference dies with LinAlgError inside pinv,
+    the batch flags them with STE_STATUS_NAN and carries on (like the batch example's try/except/continue)."""
+    from track_estimators import batch
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import generate_dts, haversine_formula, heading
+
+    g = np.load(os.path.join(GOLDEN, "modern_ships.npz"))
+    csv = os.path.join(GOLDEN, "data", "modern_ship_data.csv.gz")
+    H = np.diag([1.0, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6]); P = np.eye(4)
+    tracks, dts, x0s = [], [], []
+    ids = [str(s) for s in g["ids"]]
+    with np.errstate(all="ignore"):
+        for sid in ids:
+            st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+            st.read_csv(csv, ship_id=sid, id_col="id", lat_col="lat", lon_col="lon")
+            z = st.get_measurements(include_sog=True, include_cog=True)
+            st.calculate_cog_rate()
+            st.calculate_sog_rate()
+            assert len(st.lon) == int(g[f"{sid}_T"]) and int((st.dts == 0).sum()) == int(g[f"{sid}_zero_dt"])
+            np.testing.assert_allclose([np.nansum(np.where(np.isfinite(z), z, 0.0)), st.dts.sum()], g[f"{sid}_zsum"],
+                                       rtol=1e-12)
+            tracks.append(st)
+            dts.append(generate_dts(st.dts, 2))
+            x0s.append(z[:, 0])
+    hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P)
+    out = batch.run_batch(hb)
+    # AMOUK05 sits in port for months; from about step 7 200 the filter itself runs away on that data (latitude passes
+    # 92 degrees, speeds of -190..160 km/h) and the trajectory becomes chaotic: two CPU restatements of the reference
+    # that differ only in the square-root algorithm end up 220 degrees of longitude apart.  Parity is therefore checked on
+    # the stable prefix of that ship and on the whole of WCE5063 (17 084 steps).  A stationary ship has speeds of ~1e-13
+    # (pure rounding), so the relative measure gets an absolute floor of 1e-3 here.
+    stable_rows = {"AMOUK05": 7000}
+    for b, sid in enumerate(ids):
+        if int(g[f"{sid}_ok"]):
+            assert not (out["status"][b] & 0x1)
+            rows = g[f"{sid}_rows"]
+            keep = rows <= stable_rows.get(sid, rows.max())
+            assert keep.sum() >= 140
+            for key in ("means", "means_smoothed"):
+                ref = g[f"{sid}_{key}"][keep]
+                err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.maximum(np.abs(ref), 1e-3))
+                assert err < 1e-6, (sid, key, err)
+            for key in ("covs", "covs_smoothed"):
+                ref = g[f"{sid}_{key}"][keep]
+                err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.max(np.abs(ref), axis=(-1, -2), keepdims=True))
+                assert err < 1e-5, (sid, key, err)
+        else:
+            assert out["status"][b] & 0x11, sid  # non-finite state and/or update index past the last observation

@@ -108,3 +108,17 @@ def test_schedule_non_dyadic_misses_updates():
     c = _case("ukf_synthetic.npz", 7)
     fires, _ = orc.update_schedule(c["dt"], c["dts"])
     assert fires.sum() == 1 and len(fires) == 200
+
+
+def test_robust_helpers_vs_reference():
+    """criterion_index / update_lambda_factor restated in the oracle vs direct calls of the reference's methods."""
+    import os
+
+    from conftest import GOLDEN
+
+    k = np.load(os.path.join(GOLDEN, "kats.npz"))
+    for i in range(8):
+        c = orc.criterion_index(k["rb_x"][i], k["H"], k["rb_z"][i], k["rb_P"][i], k["R"])
+        assert np.isclose(c, k["rb_ci"][i], rtol=1e-12)
+        lam = orc.update_lambda_factor(k["rb_x"][i], k["H"], 1.0, c, 50.0, k["rb_z"][i], k["rb_P"][i], k["R"])
+        assert np.isclose(lam, k["rb_lambda"][i], rtol=1e-12)
