@@ -209,9 +209,9 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
                 crr[:N, b] = np.nan
         if have_noise:
             nb = noise[b]
-            npred[:N, :, b] = nb["noise_pred"]
-            nupd[: N + 1, :, b] = nb["noise_upd"]
-            nrts[:N, :, b] = nb["noise_rts"]
+            npred[:N, :, b] = np.asarray(nb["noise_pred"])[:N]
+            nupd[: N + 1, :, b] = np.asarray(nb["noise_upd"])[: N + 1]
+            nrts[:N, :, b] = np.asarray(nb["noise_rts"])[:N]
     same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
     return HostBatch(B=B, Nmax=Nmax, Tmax=Tmax, H=H, Q=Q, R=R, nsteps=nsteps, x0=x0, P0=P0p, dt=dt, sog_rate=sr,
                      cog_rate=cr, sog_rate_rts=None if same_rts else srr, cog_rate_rts=None if same_rts else crr,
