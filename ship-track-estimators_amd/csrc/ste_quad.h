@@ -142,17 +142,23 @@ __device__ __forceinline__ bool quad_jacobi_round(double (&A)[4], double (&V)[4]
     return go;
 }
 
-// Sweeps until no lane of the wave rotates any more.  A: row q of the symmetric matrix (XOR order), destroyed (slot 0
-// ends as eigenvalue q).  V: row q of the accumulated eigenvectors (XOR order), initialised by the caller.
+// Sweeps until no pair of any track in the wave needs a rotation.  A: row q of the symmetric matrix (XOR order),
+// destroyed (slot 0 ends as eigenvalue q).  V: row q of the accumulated eigenvectors (XOR order), initialised by the
+// caller.  The rounds are branch-free (a converged pair rotates by the identity), so a sweep in which nothing rotates
+// would cost as much as a productive one; the same criterion the rounds apply is therefore evaluated up front -- three
+// fetches of the partners' diagonal entries -- and the loop ends as soon as no lane of the wave asks for a sweep.
 __device__ __forceinline__ bool quad_jacobi_sweeps(double (&A)[4], double (&V)[4], const QuadCtx& cx) {
-    bool rotated = true;
-    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-        rotated = quad_jacobi_round<1>(A, V, cx);
-        rotated |= quad_jacobi_round<2>(A, V, cx);
-        rotated |= quad_jacobi_round<3>(A, V, cx);
-        if (!__any(rotated)) break;
+    for (int sweep = 0; sweep <= kMaxSweeps; ++sweep) {
+        const double d1 = fetch<1>(A[0]), d2 = fetch<2>(A[0]), d3 = fetch<3>(A[0]);
+        const bool need = (A[1] * A[1] > kRotTol2 * fabs(A[0] * d1)) || (A[2] * A[2] > kRotTol2 * fabs(A[0] * d2)) ||
+                          (A[3] * A[3] > kRotTol2 * fabs(A[0] * d3));
+        if (!__any(need)) return true;
+        if (sweep == kMaxSweeps) break;
+        quad_jacobi_round<1>(A, V, cx);
+        quad_jacobi_round<2>(A, V, cx);
+        quad_jacobi_round<3>(A, V, cx);
     }
-    return !rotated;
+    return false;
 }
 
 // B = V^T A V in XOR order (A, V XOR-order rows); A is overwritten with B.
