@@ -10,7 +10,7 @@
 //   gp_potrf       blocked left-looking Cholesky, one workgroup per matrix, tile products on fp64 MFMA
 //   gp_trtri       U = L^-T (upper, row-major), one workgroup per (matrix, block row)
 //   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised) -> gradient
-//   gp_alpha_lml   alpha = U (U^T y), log-marginal likelihood
+//   gp_w / gp_alpha / gp_quad / gp_finish   alpha = U (U^T y), log-marginal likelihood, gradient assembly
 //   gp_kstar / gp_predict   posterior mean and variance at new times (variance as a tile GEMM against K^-1)
 //
 // All dense work is 64x64-tile "NT" products C += A_rows * B_rows^T with both operands row-major and contiguous along
@@ -63,11 +63,11 @@ __device__ __forceinline__ void wave_gemm_nt(v4d (&acc)[2][2], const double* __r
     const double* pa1 = pa0 + 16 * lda;
     const double* pb0 = Bm + (size_t)r * ldb + 4 * g;
     const double* pb1 = pb0 + 16 * ldb;
-    for (int k = k0; k < k1; k += 16) {
-        const v4d a0 = *reinterpret_cast<const v4d*>(pa0 + k);
-        const v4d a1 = *reinterpret_cast<const v4d*>(pa1 + k);
-        const v4d b0 = *reinterpret_cast<const v4d*>(pb0 + k);
-        const v4d b1 = *reinterpret_cast<const v4d*>(pb1 + k);
+    if (k0 >= k1) return;
+    // Software pipeline without register shuffling: two named fragment sets ping-pong, each reloaded (for the chunk 32
+    // further on) right after its 16 MFMAs were issued, so one chunk of loads is always in flight behind 1024 cycles of
+    // matrix work.  Every k-range in this file is a multiple of 64 long.
+    auto mma = [&](const v4d& a0, const v4d& a1, const v4d& b0, const v4d& b1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], acc[0][0], 0, 0, 0);
@@ -75,6 +75,20 @@ __device__ __forceinline__ void wave_gemm_nt(v4d (&acc)[2][2], const double* __r
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b0[e], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], acc[1][1], 0, 0, 0);
         }
+    };
+    v4d pa_0 = *reinterpret_cast<const v4d*>(pa0 + k0), pa_1 = *reinterpret_cast<const v4d*>(pa1 + k0);
+    v4d pb_0 = *reinterpret_cast<const v4d*>(pb0 + k0), pb_1 = *reinterpret_cast<const v4d*>(pb1 + k0);
+    for (int k = k0; k < k1; k += 32) {
+        const v4d qa_0 = *reinterpret_cast<const v4d*>(pa0 + k + 16), qa_1 = *reinterpret_cast<const v4d*>(pa1 + k + 16);
+        const v4d qb_0 = *reinterpret_cast<const v4d*>(pb0 + k + 16), qb_1 = *reinterpret_cast<const v4d*>(pb1 + k + 16);
+        mma(pa_0, pa_1, pb_0, pb_1);
+        if (k + 32 < k1) {
+            pa_0 = *reinterpret_cast<const v4d*>(pa0 + k + 32);
+            pa_1 = *reinterpret_cast<const v4d*>(pa1 + k + 32);
+            pb_0 = *reinterpret_cast<const v4d*>(pb0 + k + 32);
+            pb_1 = *reinterpret_cast<const v4d*>(pb1 + k + 32);
+        }
+        mma(qa_0, qa_1, qb_0, qb_1);
     }
 }
 
@@ -343,78 +357,78 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
     }
     __syncthreads();
     if (tid < 3) {
-        // one slot per tile, summed in tile order by gp_alpha_lml: bitwise reproducible, unlike an atomic accumulation
+        // one slot per tile, summed in tile order by gp_finish: bitwise reproducible, unlike an atomic accumulation
         const int ntiles = p.nb_max * (p.nb_max + 1) / 2;
         p.tr[((size_t)b * 3 + tid) * ntiles + tile] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// alpha = U (U^T y), lml, gradient assembly.  One workgroup per matrix; n^2 work, memory bound.
+// alpha = U (U^T y), lml, gradient assembly: three small kernels, nb workgroups per matrix for the O(n^2) parts.
+//   gp_w      w = U^T y for one 64-column block        (thread per column, 8 rows in flight per thread)
+//   gp_alpha  alpha for one 64-row block + that block's share of y.alpha, log-det, alpha^T dK alpha
+//   gp_finish sums the per-block shares in block order (deterministic) -> lml, gradient
+// w lives in the Dinv buffer (free once gp_trtri has run); per-block shares go to the tail of the same buffer.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_alpha_lml(const GpParams p) {
-    extern __shared__ double sh[];  // w[nout][npad]
-    __shared__ double red[8][4];
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+__device__ __forceinline__ double* gp_wbuf(const GpParams& p, int b) { return p.Dinv + (size_t)b * p.nb_max * T * T; }
+__device__ __forceinline__ double* gp_share(const GpParams& p, int b) { return gp_wbuf(p, b) + (size_t)p.nout * p.ld; }
+
+__global__ __launch_bounds__(64) void gp_w(const GpParams p) {
+    const int b = blockIdx.y, kb = blockIdx.x, lane = threadIdx.x;
+    const int n = p.n[b], nb = nblocks(n);
+    if (kb >= nb) return;
+    const size_t ld = p.ld;
+    const double* U = p.U + (size_t)b * ld * ld;
+    const int k = kb * T + lane;
+    const int amax = (k < n ? k : n - 1);
+    for (int o = 0; o < p.nout; ++o) {
+        const double* y = p.y + ((size_t)b * p.nout + o) * p.nmax;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int a = 0;
+        for (; a + 8 <= amax + 1; a += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fma(U[(size_t)(a + u) * ld + k], y[a + u], acc[u]);
+        }
+        for (; a <= amax; ++a) acc[0] = fma(U[(size_t)a * ld + k], y[a], acc[0]);
+        gp_wbuf(p, b)[(size_t)o * ld + k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
+    __shared__ double red[5][4];
+    const int b = blockIdx.y, ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n), npad = nb * T;
+    if (ab >= nb) return;
     const size_t ld = p.ld;
     const double* U = p.U + (size_t)b * ld * ld;
     const double* L = p.K + (size_t)b * ld * ld;
     const double* x = p.x + (size_t)b * p.nmax;
-    const int nout = p.nout;
-    // w = U^T y : w[k] = sum_{a <= k} U[a][k] y[a]   (thread per column k: coalesced across the wave)
-    for (int o = 0; o < nout; ++o) {
-        const double* y = p.y + ((size_t)b * nout + o) * p.nmax;
-        for (int k = tid; k < npad; k += 256) {
+    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
+    double yta = 0.0, sl = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    for (int o = 0; o < p.nout; ++o) {
+        const double* y = p.y + ((size_t)b * p.nout + o) * p.nmax;
+        const double* w = gp_wbuf(p, b) + (size_t)o * ld;
+        double* al = p.alpha + ((size_t)b * p.nout + o) * p.nmax;
+        for (int r = wave; r < T; r += 4) {
+            const int a = ab * T + r;
+            if (a >= n) continue;
             double acc = 0.0;
-            const int amax = k < n ? k : n - 1;
-            for (int a = 0; a <= amax; ++a) acc = fma(U[(size_t)a * ld + k], y[a], acc);
-            sh[o * npad + k] = acc;
-        }
-    }
-    __syncthreads();
-    // alpha[a] = sum_{k >= a} U[a][k] w[k]   (wave per row)
-    double yta = 0.0;  // sum_o y_o . alpha_o
-    for (int o = 0; o < nout; ++o) {
-        const double* y = p.y + ((size_t)b * nout + o) * p.nmax;
-        double* al = p.alpha + ((size_t)b * nout + o) * p.nmax;
-        for (int a = wave; a < n; a += 4) {
-            double acc = 0.0;
-            for (int k = a + lane; k < npad; k += 64) acc = fma(U[(size_t)a * ld + k], sh[o * npad + k], acc);
+            for (int k = a + lane; k < npad; k += 64) acc = fma(U[(size_t)a * ld + k], w[k], acc);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
             if (lane == 0) {
                 al[a] = acc;
                 yta += y[a] * acc;
+                q2 += acc * acc;
+                if (o == 0) sl += log(L[(size_t)a * ld + a]);
             }
         }
     }
-    // sum log diag L
-    double sl = 0.0;
-    for (int i = tid; i < n; i += 256) sl += log(L[(size_t)i * ld + i]);
-    // alpha^T G alpha for the two RBF derivatives (n^2 exps) and alpha.alpha for the noise term
-    __syncthreads();
-    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
     if (p.grad) {
-        const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
-        for (int o = 0; o < nout; ++o) {
-            const double* al = p.alpha + ((size_t)b * nout + o) * p.nmax;
-            for (int i = wave; i < n; i += 4) {
-                const double ai = al[i], xi = x[i];
-                double r0 = 0.0, r1 = 0.0;
-                for (int j = lane; j < n; j += 64) {
-                    const double d = (xi - x[j]) * inv_l, d2 = d * d;
-                    const double kr = c * exp(-0.5 * d2) * al[j];
-                    r0 += kr;
-                    r1 += kr * d2;
-                }
-                q0 += ai * r0;
-                q1 += ai * r1;
-                if (lane == 0) q2 += ai * ai;
-            }
-        }
+        // alpha^T (dK/dtheta) alpha restricted to the rows of this block needs the whole alpha vector, which the other
+        // blocks of the grid are still producing: gp_quad (next launch) does it.
     }
-    double vals[6] = {yta, sl, q0, q1, q2, 0.0};
+    double vals[5] = {yta, sl, q0, q1, q2};
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
         double t = vals[v];
@@ -423,23 +437,71 @@ __global__ __launch_bounds__(256) void gp_alpha_lml(const GpParams p) {
         if (lane == 0) red[v][wave] = t;
     }
     __syncthreads();
-    if (tid == 0) {
-        double r[5];
-        for (int v = 0; v < 5; ++v) r[v] = red[v][0] + red[v][1] + red[v][2] + red[v][3];
-        p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
-        if (p.grad) {
-            const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = nb * (nb + 1) / 2;
-            double tr[3];
-            for (int v = 0; v < 3; ++v) {
-                double acc = 0.0;
-                for (int i = 0; i < mine; ++i) acc += p.tr[((size_t)b * 3 + v) * ntiles + i];
-                tr[v] = acc;
+    if (tid < 5) gp_share(p, b)[(size_t)tid * p.nb_max + ab] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    (void)x; (void)c; (void)inv_l;
+}
+
+// alpha^T Krbf alpha and alpha^T (Krbf o d^2) alpha, rows of one 64-row block against all columns (n^2 exps per output,
+// spread over nb workgroups per matrix).
+__global__ __launch_bounds__(256) void gp_quad(const GpParams p) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.y, ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = p.n[b], nb = nblocks(n);
+    if (ab >= nb) return;
+    const double* x = p.x + (size_t)b * p.nmax;
+    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
+    double q0 = 0.0, q1 = 0.0;
+    for (int o = 0; o < p.nout; ++o) {
+        const double* al = p.alpha + ((size_t)b * p.nout + o) * p.nmax;
+        for (int r = wave; r < T; r += 4) {
+            const int i = ab * T + r;
+            if (i >= n) continue;
+            const double ai = al[i], xi = x[i];
+            double r0 = 0.0, r1 = 0.0;
+            for (int j = lane; j < n; j += 64) {
+                const double d = (xi - x[j]) * inv_l, d2 = d * d;
+                const double kr = c * exp(-0.5 * d2) * al[j];
+                r0 += kr;
+                r1 += kr * d2;
             }
-            const double s = exp(p.theta[b * 3 + 2]);
-            p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * tr[0]);
-            p.grad[b * 3 + 1] = 0.5 * (r[3] - nout * tr[1]);
-            p.grad[b * 3 + 2] = 0.5 * s * (r[4] - nout * tr[2]);
+            q0 += ai * r0;
+            q1 += ai * r1;
         }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        q0 += __shfl_xor(q0, off);
+        q1 += __shfl_xor(q1, off);
+    }
+    if (lane == 0) {
+        red[0][wave] = q0;
+        red[1][wave] = q1;
+    }
+    __syncthreads();
+    if (tid < 2) gp_share(p, b)[(size_t)(2 + tid) * p.nb_max + ab] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+__global__ __launch_bounds__(64) void gp_finish(const GpParams p) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= p.B) return;
+    const int n = p.n[b], nb = nblocks(n), nout = p.nout;
+    const double* sh = gp_share(p, b);
+    double r[5] = {0, 0, 0, 0, 0};
+    for (int v = 0; v < 5; ++v)
+        for (int i = 0; i < nb; ++i) r[v] += sh[(size_t)v * p.nb_max + i];
+    p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
+    if (p.grad) {
+        const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = nb * (nb + 1) / 2;
+        double tr[3];
+        for (int v = 0; v < 3; ++v) {
+            double acc = 0.0;
+            for (int i = 0; i < mine; ++i) acc += p.tr[((size_t)b * 3 + v) * ntiles + i];
+            tr[v] = acc;
+        }
+        const double s = exp(p.theta[b * 3 + 2]);
+        p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * tr[0]);
+        p.grad[b * 3 + 1] = 0.5 * (r[3] - nout * tr[1]);
+        p.grad[b * 3 + 2] = 0.5 * s * (r[4] - nout * tr[2]);
     }
 }
 
@@ -616,8 +678,10 @@ int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
     hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_trtri, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(tiles, p.B), dim3(256), 0, s, p, b->Kinv);
-    const size_t shmem = sizeof(double) * (size_t)p.nout * p.ld;
-    hipLaunchKernelGGL(stegp::gp_alpha_lml, dim3(p.B), dim3(256), shmem, s, p);
+    hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, p.B), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
+    if (p.grad) hipLaunchKernelGGL(stegp::gp_quad, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_finish, dim3((p.B + 63) / 64), dim3(64), 0, s, p);
     return gp_hip(hipGetLastError(), "gp_lml launch");
 }
 
