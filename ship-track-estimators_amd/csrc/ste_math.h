@@ -27,16 +27,35 @@ struct Mats {
     int robust_iters;  // 0 = robustification off (the reference's call site is commented out, unscented.py:228)
 };
 
-// NumPy floored modulo for a positive divisor (unscented.py:250,257,340,346): fmod, then shift negatives up by b,
-// and an exact zero takes the sign of b (npy_divmod).
-__device__ __forceinline__ double floored_mod(double a, double b) {
-    double r = fmod(a, b);
-    if (r != 0.0) {
-        if (r < 0.0) r += b;
-    } else {
-        r = 0.0;  // copysign(0, b) with b > 0; NaN stays NaN through the other branch
+// NumPy floored modulo by 360 (unscented.py:250,257,340,346): npy_divmod takes fmod(a, b) (exact) and, when that is
+// negative, adds b once (one rounding); an exact zero comes out as +0.  Here: q = floor(a/360) estimated with one
+// multiply, r = fma(-q, 360, a) -- the product is exact and the difference is representable, so r IS a - 360 q -- and if
+// the estimate was off by one the remainder is recomputed with the neighbouring q.  The result equals NumPy's bit for
+// bit (for a >= 0 it is the exact remainder; for a < 0 it is the correctly rounded fmod(a, 360) + 360).
+__device__ __forceinline__ double floored_mod360(double a) {
+    if (__builtin_expect(!(fabs(a) < 1e15), 0)) {  // q * 360 would no longer be exact; also inf / NaN
+        double r = fmod(a, 360.0);
+        if (r != 0.0) {
+            if (r < 0.0) r += 360.0;
+        } else {
+            r = 0.0;
+        }
+        return r;
+    }
+    double q = floor(a * 2.7777777777777778e-03);
+    double r = fma(-q, 360.0, a);
+    if (r < 0.0) {
+        q -= 1.0;
+        r = fma(-q, 360.0, a);
+    } else if (r >= 360.0) {
+        q += 1.0;
+        r = fma(-q, 360.0, a);
     }
     return r;
+}
+__device__ __forceinline__ double floored_mod(double a, double b) {
+    (void)b;  // every call site of the reference uses 360
+    return floored_mod360(a);
 }
 
 // (y + 180) % 360 - 180   (unscented.py:250, :340)

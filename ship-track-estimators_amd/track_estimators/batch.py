@@ -111,6 +111,7 @@ class HostBatch:
     robust: bool = False  # opt-in Mahalanobis robust update (not on the reference's shipped path)
     chi_alpha: float = 50.0
     host_status: Optional[np.ndarray] = None  # (B,) int32 bits set while packing (STATUS_HOST_INDEX)
+    order: Optional[np.ndarray] = None  # (B,) batch slot -> index of the caller's track (length-bucketed packing)
 
     @property
     def shared_p0(self) -> bool:
@@ -133,7 +134,8 @@ STATUS_HOST_INDEX = 0x10  # the reference would raise IndexError for this track 
 
 
 def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, R, P0, t0s=None,
-                noise: Optional[Sequence[dict]] = None, on_error: str = "flag") -> HostBatch:
+                noise: Optional[Sequence[dict]] = None, on_error: str = "flag",
+                bucket_by_length: bool = True) -> HostBatch:
     """
     Pack B tracks (objects carrying ``z`` (4,T), ``dts`` (T-1,), ``sog_rate`` (T,), ``cog_rate`` (T,) like a
     reference ``ShipTrack``, ship_track.py:70-83) with their per-track ``dt`` arrays and priors into a HostBatch.
@@ -143,10 +145,26 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
     float-equality trigger fire twice per gap) raises IndexError in the reference (kalman_filter.py:105).  "raise" does
     the same; "flag" (default, the batch example's try/except/continue) truncates that track at the offending step and
     sets STATUS_HOST_INDEX in ``host_status``.
+    ``bucket_by_length``: tracks are laid out longest first, so that the 16 or 64 tracks sharing a wave have similar
+    step counts and the wave does not idle through the tail of one long track (real data: 30 .. 9 619 observations per
+    ship).  ``HostBatch.order`` records the permutation; ``run_batch`` returns results in the caller's order.
     """
     B = len(tracks)
     if B == 0:
         raise ValueError("empty batch")
+    order = None
+    if bucket_by_length and B > 1:
+        lens = np.array([len(d) for d in dts_per_track])
+        if len(set(lens.tolist())) > 1:
+            order = np.argsort(-lens, kind="stable")
+            tracks = [tracks[i] for i in order]
+            dts_per_track = [dts_per_track[i] for i in order]
+            x0s = [x0s[i] for i in order]
+            t0s = None if t0s is None else [t0s[i] for i in order]
+            noise = None if noise is None else [noise[i] for i in order]
+            P0a = np.asarray(P0, dtype=np.float64)
+            if P0a.ndim == 3:
+                P0 = P0a[order]
     H, Q, R = _as44(H, "H"), _as44(Q, "Q"), _as44(R, "R")
     Ns = [len(d) for d in dts_per_track]
     Ts = [np.asarray(tr.z).shape[1] for tr in tracks]
@@ -215,7 +233,8 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
     same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
     return HostBatch(B=B, Nmax=Nmax, Tmax=Tmax, H=H, Q=Q, R=R, nsteps=nsteps, x0=x0, P0=P0p, dt=dt, sog_rate=sr,
                      cog_rate=cr, sog_rate_rts=None if same_rts else srr, cog_rate_rts=None if same_rts else crr,
-                     upd_idx=ui, z=z, noise_pred=npred, noise_upd=nupd, noise_rts=nrts, host_status=host_status)
+                     upd_idx=ui, z=z, noise_pred=npred, noise_upd=nupd, noise_rts=nrts, host_status=host_status,
+                     order=order)
 
 
 def pack_uniform(sb, substeps: int, H, Q, R, P0) -> HostBatch:
@@ -355,4 +374,8 @@ def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: b
     out["means"], out["covs"] = db.filtered()
     if smooth:
         out["means_smoothed"], out["covs_smoothed"] = db.smoothed()
+    if hb.order is not None:  # back to the caller's track order
+        inv = np.empty_like(hb.order)
+        inv[hb.order] = np.arange(len(hb.order))
+        out = {k: v[inv] for k, v in out.items()}
     return out

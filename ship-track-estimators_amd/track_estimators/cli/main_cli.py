@@ -150,7 +150,7 @@ def track_estimator(argv=None):
             if out["status"][b] & 0x1:
                 logger.error(f"Error in {sid}: non-finite state (the reference raises LinAlgError here); skipped.")
                 continue
-            n1 = hb.nsteps[b] + 1
+            n1 = out["nsteps"][b] + 1
             sm = (out["means_smoothed"][b, :n1], out["covs_smoothed"][b, :n1]) if args.apply_rts_smoother else None
             _write_outputs(args.output_prefix, sid, tracks[b], dts[b], out["means"][b, :n1], out["covs"][b, :n1], sm)
     exit_banner()

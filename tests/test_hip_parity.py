@@ -94,7 +94,7 @@ def test_golden_ragged_batch():
         assert cov_err(out["covs_smoothed"][b, : N + 1], c["covs_smoothed"]) < COV_TOL
     # identical tracks in different batch positions give identical bits (no cross-track coupling)
     for b in range(len(cs), hb.B):
-        N = hb.nsteps[b]
+        N = out["nsteps"][b]
         assert np.array_equal(out["means_smoothed"][b, : N + 1], out["means_smoothed"][b % len(cs), : N + 1])
 
 
@@ -167,3 +167,47 @@ def test_single_function_kernels():
         torch.cuda.synchronize()
         got = sig.cpu().numpy().transpose(2, 1, 0)  # (n, 4, 9) like the reference's (n_state, n_sigma)
         np.testing.assert_allclose(got, k[key], rtol=0, atol=1e-11)
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json configs[1] at full size (10 000 tracks x 500 steps) through size-independent properties:
+    no status flags, identical tracks in different batch slots give identical bits, the two lane mappings agree, and a
+    sample of tracks matches the oracle."""
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+    from track_estimators._hip import binding
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    nuniq, B = 2500, 10_000
+    sbu = synthetic.make_batch(nuniq, nobs=126, gap_h=1.0, seed0=10_000)
+    idx = np.concatenate([np.arange(nuniq), np.random.default_rng(0).permutation(np.arange(nuniq).repeat(3))])
+    sb = synthetic.SyntheticBatch(**{f.name: getattr(sbu, f.name)[idx] for f in __import__("dataclasses").fields(sbu)})
+    hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    assert hb.B == B and hb.Nmax == 500
+    lib = binding.load()
+    res = {}
+    for lanes in (1, 4):
+        lib.ste_set_lanes_per_track(lanes)
+        db = batch.DeviceBatch(hb)
+        db.run()
+        db.torch.cuda.synchronize()
+        assert not db.status_host().any()
+        res[lanes] = db.sm_mean.cpu().numpy()  # [N+1][4][B]
+        first = np.full(nuniq, -1)
+        for slot, src in enumerate(idx):
+            if first[src] < 0:
+                first[src] = slot
+        dup = np.arange(B)[first[idx] != np.arange(B)]
+        assert np.array_equal(res[lanes][:, :, dup], res[lanes][:, :, first[idx[dup]]])
+        del db
+    a, b = res[1], res[4]
+    assert np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-12)) < 1e-7
+    n = 48
+    fires = hb.upd_idx.T[:n] >= 0
+    zidx = np.where(fires, hb.upd_idx.T[:n], 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
+    rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (n, 500))
+    sm, _ = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
+    got = res[4][:, :, :n].transpose(2, 0, 1)
+    assert mean_err(got, sm) < MEAN_TOL

@@ -81,7 +81,8 @@ def test_pack_tracks_layout_and_ragged_padding():
 
     cs = load_cases("ukf_synthetic.npz")[:4] + load_cases("ukf_synthetic.npz")[7:8]
     tr = [types.SimpleNamespace(z=c["z"], dts=c["dts"], sog_rate=c["sog_rate"], cog_rate=c["cog_rate"]) for c in cs]
-    hb = batch.pack_tracks(tr, [c["dt"] for c in cs], [c["x0"] for c in cs], cs[0]["H"], cs[0]["Q"], cs[0]["R"], cs[0]["P0"])
+    hb = batch.pack_tracks(tr, [c["dt"] for c in cs], [c["x0"] for c in cs], cs[0]["H"], cs[0]["Q"], cs[0]["R"], cs[0]["P0"],
+                           bucket_by_length=False)
     assert hb.B == 5 and hb.Nmax == 500 and hb.Tmax == 501 and hb.shared_p0
     assert hb.nsteps.tolist() == [500, 500, 500, 500, 200]
     for b, c in enumerate(cs):
@@ -99,6 +100,22 @@ def test_pack_tracks_layout_and_ragged_padding():
     assert np.array_equal(hb.sog_rate_rts[:200, 4], np.repeat(c["sog_rate"], 10)[:200])
     with pytest.raises(ValueError):
         batch.pack_tracks(tr, [c["dt"] for c in cs], [c["x0"] for c in cs], np.eye(2), cs[0]["Q"], cs[0]["R"], cs[0]["P0"])
+
+
+def test_length_bucketing_permutation():
+    """Ragged batches are laid out longest-first; ``order`` maps batch slots back to the caller's tracks."""
+    from track_estimators import batch
+
+    cs = load_cases("ukf_synthetic.npz")
+    pick = [7, 0, 9, 1]  # N = 200, 500, 117, 500
+    tr = [types.SimpleNamespace(z=cs[i]["z"], dts=cs[i]["dts"], sog_rate=cs[i]["sog_rate"], cog_rate=cs[i]["cog_rate"]) for i in pick]
+    hb = batch.pack_tracks(tr, [cs[i]["dt"] for i in pick], [cs[i]["x0"] for i in pick], cs[0]["H"], cs[0]["Q"], cs[0]["R"], cs[0]["P0"])
+    assert hb.order.tolist() == [1, 3, 0, 2] and hb.nsteps.tolist() == [500, 500, 200, 117]
+    for slot, src in enumerate(hb.order):
+        c = cs[pick[src]]
+        assert np.array_equal(hb.dt[: len(c["dt"]), slot], c["dt"]) and np.array_equal(hb.x0[:, slot], c["x0"])
+    same = batch.pack_tracks(tr[1:2] * 3, [cs[0]["dt"]] * 3, [cs[0]["x0"]] * 3, cs[0]["H"], cs[0]["Q"], cs[0]["R"], cs[0]["P0"])
+    assert same.order is None  # nothing to reorder when all lengths are equal
 
 
 def test_pack_uniform_equals_pack_tracks():
