@@ -36,7 +36,7 @@ BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mea
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
 # Measured HBM bytes per track-step (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.csv).
 # Above the algorithmic figure by the rts_work rows the forward pass hands to the smoother.
-TRAFFIC_FWD = 438
+TRAFFIC_FWD = 441
 TRAFFIC_BWD = 337 + 560  # urtss_gain_kernel + urtss_combine_l1
 FLOPS_PER_TRACK_STEP = 2.0e4  # SURVEY.md §8d estimate (fp64 flop-equivalents, forward + backward)
 
@@ -183,9 +183,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": dom_traffic * track_steps_rank if (args.lanes in (0, 1) and db.rts_work is not None) else None,
+                "traffic": dom_traffic * track_steps_rank if db.rts_work is not None else None,
                 "traffic_unit": "bytes per launch",
-                "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_v6_quad.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                                   "passes of this command; FETCH_SIZE doubled per the gfx950 calibration in profiles/README.md)",
                 "algorithmic_bytes_per_track_step": dom_bytes,
                 "pair_achieved": pair_gbs,
