@@ -1,28 +1,37 @@
 """
-Command-line flags of ``track_estimator``.  Same flags, destinations and defaults as the reference
-(/root/reference/src/track_estimators/cli/argument_parser.py:7-93); ``--no-noise`` and a comma-separated ``-s`` are
-additive extras.
+Command-line surface of ``track_estimator``.
+
+The flag names, destinations and defaults are the reference's (cli/argument_parser.py:14-91 there), because scripts such
+as its examples/cli_example/run.sh must keep working; they are declared here as one table.  ``--no-noise`` and a
+comma-separated ``-s`` are additive extras of this build.
 """
 import argparse
 
 from .. import __version__
 
+# (short, long, dest, kwargs)
+_OPTIONS = (
+    ("-i", "--input", "input_file", dict(default="input.json", help="Filepath to the input JSON file")),
+    ("-o", "--output", "output_prefix", dict(default="output", help="Output file prefix")),
+    ("-t", "--track-file", "track_file", dict(required=True, help="Filepath to the ship track data")),
+    ("-s", "--ship-id", "ship_id", dict(required=True, help="Ship ID; several comma-separated IDs are filtered in one "
+                                                           "batched GPU launch")),
+    ("-lat", "--latitude-id", "lat_id", dict(required=True, help="Name of the latitude column")),
+    ("-lon", "--longitude-id", "lon_id", dict(required=True, help="Name of the longitude column")),
+    ("-ic", "--id-col", "id_col", dict(required=True, help="Name of the ship ID column")),
+    ("-rts", "--rts-smoother", "apply_rts_smoother", dict(action="store_true",
+                                                          help="Apply the Rauch-Tung-Striebel (RTS) smoother")),
+    ("-rev", "--reverse", "reverse", dict(action="store_true", help="Reverse the trajectory")),
+    (None, "--no-noise", "no_noise", dict(action="store_true", help="Skip the process/measurement noise the reference "
+                                                                    "injects (deterministic output)")),
+)
+
 
 def create_parser():
-    parser = argparse.ArgumentParser(description=f"Ship track estimator {__version__} command line interface",
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("-i", "--input", dest="input_file", default="input.json", help="Filepath to the input JSON file")
-    parser.add_argument("-o", "--output", dest="output_prefix", default="output", help="Output file prefix")
-    parser.add_argument("-t", "--track-file", dest="track_file", required=True, help="Filepath to the ship track data")
-    parser.add_argument("-s", "--ship-id", dest="ship_id", required=True,
-                        help="Ship ID (several comma-separated IDs are filtered in one batched GPU launch)")
-    parser.add_argument("-lat", "--latitude-id", dest="lat_id", required=True, help="Name of the latitude column")
-    parser.add_argument("-lon", "--longitude-id", dest="lon_id", required=True, help="Name of the longitude column")
-    parser.add_argument("-ic", "--id-col", dest="id_col", required=True, help="Name of the ship ID column")
-    parser.add_argument("-rts", "--rts-smoother", dest="apply_rts_smoother", action="store_true",
-                        help="Apply the Rauch-Tung-Striebel (RTS) smoother")
-    parser.add_argument("-rev", "--reverse", dest="reverse", action="store_true", help="Reverse the trajectory")
-    parser.add_argument("--no-noise", dest="no_noise", action="store_true",
-                        help="Do not inject the process/measurement noise the reference draws (deterministic output)")
-    parser.add_argument("-v", "--version", action="version", version="%(prog)s {version}".format(version=__version__))
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                     description=f"Ship track estimator {__version__} command line interface")
+    for short, long_, dest, kw in _OPTIONS:
+        names = [n for n in (short, long_) if n]
+        parser.add_argument(*names, dest=dest, **kw)
+    parser.add_argument("-v", "--version", action="version", version=f"%(prog)s {__version__}")
     return parser
