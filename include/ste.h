@@ -190,8 +190,11 @@ int ste_sigma_points_generic_f64(int32_t n, int64_t count, const double* x, cons
  * track b has n[b] observations at 1-D inputs x (cumulative time, gaussian_process.py:53-58) with nout outputs
  * (lon, lat: :66) and its own kernel hyper-parameters theta = log(constant, length_scale, noise) of
  * ConstantKernel * RBF + WhiteKernel (examples/example_gaussian_process_batch.py:41).
- * Matrices are row-major [B][ld][ld] with ld = 64 * ceil(nmax / 64); all buffers are caller-owned device memory.
+ * Matrices are row-major [B][ld][ld] with ld = 64 * ceil(nmax / 64) + STE_GP_LD_PAD (the pad keeps consecutive rows off
+ * the same HBM channel when 64 * ceil(nmax / 64) is a power of two); all buffers are caller-owned device memory.
  * ------------------------------------------------------------------------------------------------------------- */
+#define STE_GP_LD_PAD 16
+
 typedef struct ste_gp_batch_f64 {
     int32_t B;     /* number of tracks */
     int32_t nmax;  /* padded number of observations */
@@ -204,12 +207,12 @@ typedef struct ste_gp_batch_f64 {
     const double* theta; /* [B][3] log(constant), log(length_scale), log(noise) */
     double* K;      /* [B][ld][ld]  K(X,X) + (noise + jitter) I, then its Cholesky factor L (lower triangle) */
     double* U;      /* [B][ld][ld]  workspace: L^-T (upper triangle) */
-    double* Dinv;   /* [B][ld/64][64][64] workspace: inverses of the diagonal blocks of L */
+    double* Dinv;   /* [B][(ld-16)/64][64][64] workspace: inverses of the diagonal blocks of L */
     double* Kinv;   /* [B][ld][ld] K^-1 (both triangles) when non-NULL; needed by ste_gp_predict_f64 */
     double* alpha;  /* [B][nout][nmax] out: K^-1 y */
     double* lml;    /* [B] out: log marginal likelihood summed over outputs */
     double* grad;   /* [B][3] out: d lml / d theta, or NULL to skip the gradient */
-    double* tr;     /* [B][3][nt] workspace, nt = (ld/64)(ld/64 + 1)/2: per-tile partial traces (summed in tile order) */
+    double* tr;     /* [B][3][nt] workspace, nt = nb(nb + 1)/2 with nb = ceil(nmax/64): per-tile partial traces (summed in tile order) */
     int32_t* status; /* [B] out: 0 ok, 1 = K not positive definite */
 } ste_gp_batch_f64;
 

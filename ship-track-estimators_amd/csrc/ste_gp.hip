@@ -628,7 +628,7 @@ int gp_params(const ste_gp_batch_f64* b, stegp::GpParams* p) {
     p->nmax = b->nmax;
     p->nb_max = (b->nmax + 63) / 64;
     p->nout = b->nout;
-    p->ld = p->nb_max * 64;
+    p->ld = p->nb_max * 64 + STE_GP_LD_PAD;
     p->n = b->n;
     p->x = b->x;
     p->y = b->y;

@@ -29,7 +29,8 @@ class GpDeviceBatch:
         self.n = np.array([len(x) for x in xs], dtype=np.int32)
         self.nout = int(np.asarray(ys[0]).reshape(len(xs[0]), -1).shape[1])
         self.nmax = int(self.n.max())
-        self.ld = 64 * ((self.nmax + 63) // 64)
+        self.nb = (self.nmax + 63) // 64
+        self.ld = 64 * self.nb + 16  # STE_GP_LD_PAD (include/ste.h)
         B, nmax, ld, nout = self.B, self.nmax, self.ld, self.nout
         xh = np.zeros((B, nmax))
         yh = np.zeros((B, nout, nmax))
@@ -45,12 +46,12 @@ class GpDeviceBatch:
         self.t_theta = torch.zeros((B, 3), **f64)
         self.t_K = torch.empty((B, ld, ld), **f64)
         self.t_U = torch.empty((B, ld, ld), **f64)
-        self.t_Dinv = torch.empty((B, ld // 64, 64, 64), **f64)
+        self.t_Dinv = torch.empty((B, self.nb, 64, 64), **f64)
         self.t_Kinv = None
         self.t_alpha = torch.zeros((B, nout, nmax), **f64)
         self.t_lml = torch.zeros((B,), **f64)
         self.t_grad = torch.zeros((B, 3), **f64)
-        nbm = ld // 64
+        nbm = self.nb
         self.t_tr = torch.zeros((B, 3, nbm * (nbm + 1) // 2), **f64)
         self.t_status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         s = binding.SteGpBatchF64()
