@@ -253,12 +253,19 @@ __global__ __launch_bounds__(256) void gp_potrf(const GpParams p) {
 // U = L^-T (upper triangular, row-major).  Row block a of U depends only on L and Dinv: one workgroup per (a, matrix).
 //   U[a][a] = Dinv_a^T ;  U[a][b] = -( sum_{k in [a, b)} U[a][k] L[b][k]^T ) Dinv_b^T   for b > a
 // ---------------------------------------------------------------------------------------------------------------
+// kPerMatrix: one workgroup walks all block rows of its matrix (grid = B).  With hundreds of matrices in flight that
+// keeps one row stream per CU instead of thousands chip-wide and measured 2x faster; small batches use one workgroup
+// per block row (grid = nb x B) for parallelism.
+template <bool kPerMatrix>
 __global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
     __shared__ double S[T * LD];
-    const int b = blockIdx.y, a = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = kPerMatrix ? blockIdx.x : blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = nblocks(p.n[b]);
-    if (a >= nb) return;
+    const int a_begin = kPerMatrix ? 0 : blockIdx.x, a_end = kPerMatrix ? nb : blockIdx.x + 1;
+    if (a_begin >= nb) return;
     const size_t ld = p.ld;
+    for (int a = a_begin; a < a_end; ++a) {
     const double* L = p.K + (size_t)b * ld * ld;
     double* U = p.U + (size_t)b * ld * ld;
     const double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
         });
         __threadfence_block();
         __syncthreads();
+    }
     }
 }
 
@@ -676,7 +684,10 @@ int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
     hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, p.B), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_trtri, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
+    if (p.B >= 128)
+        hipLaunchKernelGGL(stegp::gp_trtri<true>, dim3(p.B), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(tiles, p.B), dim3(256), 0, s, p, b->Kinv);
     hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, p.B), dim3(64), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
