@@ -211,3 +211,31 @@ def test_full_size_batch_properties():
     sm, _ = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
     got = res[4][:, :, :n].transpose(2, 0, 1)
     assert mean_err(got, sm) < MEAN_TOL
+
+
+def test_degenerate_shapes():
+    """Tracks with zero steps, a single observation, and batches that do not fill a wave or a quad group."""
+    import types
+
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(3, nobs=5, gap_h=1.0, seed0=91)
+    tr = [types.SimpleNamespace(z=sb.z[i], dts=sb.dts[i], sog_rate=sb.sog_rate[i], cog_rate=sb.cog_rate[i]) for i in range(3)]
+    dts = [np.repeat(sb.dts[0] / 2, 2), np.zeros(0), np.repeat(sb.dts[2] / 2, 2)[:3]]  # 8 steps, 0 steps, 3 steps
+    hb = batch.pack_tracks(tr, dts, [sb.z[i][:, 0] for i in range(3)], H, Q, R, P0)
+    out = batch.run_batch(hb)
+    assert out["nsteps"].tolist() == [8, 0, 3] and not out["status"].any()
+    # zero steps: history row 0 is the prior, and the smoother leaves it alone
+    assert np.array_equal(out["means"][1, 0], sb.z[1][:, 0]) and np.array_equal(out["means_smoothed"][1, 0], sb.z[1][:, 0])
+    assert np.array_equal(out["covs"][1, 0], P0)
+    for b in (0, 2):
+        m, P = orc.forward_track(sb.z[b][:, 0], P0, H, Q, R, dts[b], sb.dts[b], sb.z[b], sb.sog_rate[b], sb.cog_rate[b])
+        n1 = len(dts[b]) + 1
+        assert mean_err(out["means"][b, :n1], m) < MEAN_TOL and cov_err(out["covs"][b, :n1], P) < COV_TOL
+    # a single observation: only the initial update can happen
+    one = types.SimpleNamespace(z=sb.z[0][:, :1], dts=np.zeros(0), sog_rate=sb.sog_rate[0][:1], cog_rate=sb.cog_rate[0][:1])
+    hb1 = batch.pack_tracks([one], [np.zeros(0)], [sb.z[0][:, 0]], H, Q, R, P0)
+    o1 = batch.run_batch(hb1)
+    assert o1["means"].shape == (1, 1, 4) and not o1["status"].any()
