@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gather even with one rank (rehearsal of the N>1 path)")
     args = ap.parse_args()
 
     import torch
@@ -83,10 +85,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
@@ -102,7 +105,7 @@ def main():
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     db = batch.DeviceBatch(hb, device=dev)
     gathered = None
-    if world > 1 and not args.no_gather:
+    if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
         gathered = distributed.OverlappedGather(hb.Nmax + 1, B, dev)
 
