@@ -700,10 +700,12 @@ __global__ __launch_bounds__(64) void ukf_forward_q4(const KParams p) {
         if (live) {
             const double dt = dt_n, sr = sr_n, cr = cr_n;
             const int ui = ui_n;
-            double zk[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ui >= 0) load_vec(p.z, (size_t)ui, B, t, zk);
-            if (k + 1 < ns) {
-                const size_t o = (size_t)(k + 1) * B + t;
+            // Unconditional loads with clamped indices: a load inside an `if` makes hipcc drain the queue with
+            // s_waitcnt vmcnt(0) where the branch rejoins, i.e. right after issuing it -- a full HBM round trip per step.
+            double zk[4];
+            load_vec(p.z, (size_t)(ui >= 0 ? ui : 0), B, t, zk);
+            {
+                const size_t o = (size_t)(k + 1 < ns ? k + 1 : k) * B + t;
                 dt_n = p.dt[o];
                 sr_n = p.sog_rate[o];
                 cr_n = p.cog_rate[o];
