@@ -197,6 +197,17 @@ def main():
                               "frac": valu_tf / FP64_VALU_PEAK_TFLOPS, "flops_per_track_step": FLOPS_PER_TRACK_STEP},
             },
         }
+        if world == 1:
+            # PCIe-inclusive rate of the host-buffer boundary (batch.run_batch: upload inputs, filter + smooth, download
+            # the four history tensors).  Reported for DESIGN.md; it is never `value`.
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            res = batch.run_batch(hb, device=dev, smooth=True)
+            t_host = time.perf_counter() - t1
+            out["pcie_inclusive"] = {"value": hb.track_steps / t_host, "unit": "track-steps/s", "seconds": t_host,
+                                     "bytes_down": int(sum(res[k].nbytes for k in ("means", "covs", "means_smoothed",
+                                                                                     "covs_smoothed")))}
+            del res
         if args.cpu_tracks > 0:
             v, secs, ref, chb = cpu_baseline(args.cpu_tracks)
             # the CPU sample is the first cpu_tracks tracks of rank 0's shard: cross-check the GPU result on it
