@@ -90,8 +90,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        # STE_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the N>1 control flow (RCCL refuses
+        # two ranks on one device); the driver's multi-GPU runs use the default, nccl = RCCL over xGMI.
+        backend = os.environ.get("STE_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     lib = binding.require_gpu()

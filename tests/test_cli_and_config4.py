@@ -185,3 +185,28 @@ def test_config4_modern_ships_batch():
                 assert err < 1e-5, (sid, key, err)
         else:
             assert out["status"][b] & 0x11, sid  # non-finite state and/or update index past the last observation
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_two_rank_control_flow():
+    """bench.py launched as two ranks by torch.distributed.run (as the driver does for N>1), both on this box's one GPU
+    with the gloo backend standing in for RCCL: checks rank handling, track sharding, the overlapped all-gather of the
+    smoothed positions, the max-over-ranks timing and the single JSON line."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, STE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--tracks", "256", "--cpu-tracks", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "track-steps/s"
+    assert out["config"]["tracks_per_gpu"] == 256 and "all-gather" in out["config"]["parallelism"]
+    assert out["value"] > 0 and out["status_flagged_tracks"] == 0
