@@ -1,9 +1,14 @@
 // ste_kernels.hip — batched UKF forward pass and unscented RTS smoother for gfx950 (MI355X), plus the C ABI of
 // include/ste.h.  fp64 throughout; no MFMA (4x4 contractions), no LDS: the whole per-track state lives in VGPRs.
 //
-// Lane mapping "L1": one lane per track, 64 tracks per wave, one wave per workgroup so that the (few) waves of a
-// 10k-track batch spread over all 256 CUs.  All per-step inputs/outputs are SoA with the track index fastest, so a
-// wave's accesses are 512-byte contiguous runs.
+// Kernels:
+//   ukf_forward_q4 / ukf_forward_l1      forward filter, one DPP quad or one lane per track (chosen by batch size);
+//                                        with rts_work they also emit the smoother's x_b, P_b and cross-covariance D
+//   urtss_gain_kernel                    K = D pinv(P_b) for every (track, step) at once -- fills the chip
+//   urtss_combine_q4 / urtss_combine_l1  the sequential smoother recurrence, HBM-bound, prefetch ring
+//   urtss_backward_l1                    stand-alone smoother that recomputes everything (rts_work == NULL)
+//   predict / update / robust_terms / geodetic / sigma_points kernels   single-step API parity
+// All per-step inputs/outputs are SoA with the track index fastest, so a wave's accesses are contiguous runs.
 //
 // Reference semantics (paths relative to /root/reference/src/track_estimators/kalman_filters/):
 //   forward  : kalman_filter.py:61-117 (driver), unscented.py:178-207 (predict), :219-265 (update)
