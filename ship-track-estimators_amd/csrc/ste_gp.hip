@@ -319,9 +319,17 @@ __global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* kinv_out) {
     __shared__ double red[3][4];
-    const int b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // XCD-aware mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with a
+    // (tile, matrix) grid one matrix's tiles would land on all eight.  Here ids that are congruent mod 8 -- the ones
+    // that share an XCD -- walk the tiles of the SAME matrix in order, so the U rows a tile row re-reads come from that
+    // XCD's L2 instead of HBM.  Placement only affects speed: every tile is still computed exactly once.
+    const int ntile_grid = p.nb_max * (p.nb_max + 1) / 2;
+    const int id = blockIdx.x, slot = id >> 3;
+    const int b = (slot / ntile_grid) * 8 + (id & 7);
+    if (b >= p.B) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n);
-    int tile = blockIdx.x;
+    int tile = slot % ntile_grid;
     int ta = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
     while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
     while (ta * (ta + 1) / 2 > tile) --ta;
@@ -688,7 +696,10 @@ int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
         hipLaunchKernelGGL(stegp::gp_trtri<true>, dim3(p.B), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
-    if (p.grad || b->Kinv) hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(tiles, p.B), dim3(256), 0, s, p, b->Kinv);
+    if (p.grad || b->Kinv) {
+        const unsigned groups = (unsigned)((p.B + 7) / 8);
+        hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * (unsigned)tiles), dim3(256), 0, s, p, b->Kinv);
+    }
     hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, p.B), dim3(64), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
     if (p.grad) hipLaunchKernelGGL(stegp::gp_quad, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
