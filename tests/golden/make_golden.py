@@ -336,6 +336,24 @@ def modern_cases():
     return out
 
 
+def two_runs_case():
+    """A second ``run`` on the same filter object appends to the history and keeps the running time
+    (kalman_filter.py:22-31,98): the update index restarts at 0 while ``self.time`` continues, so the float-equality
+    trigger of the second run is evaluated against times offset by the first run's span."""
+    H, Q, R, P = synthetic.example_matrices()
+    sb = synthetic.make_batch(1, nobs=9, gap_h=1.0, seed0=77)
+    st = ship_track_from_arrays(sb, 0)
+    x0 = st.z[:, 0].reshape(-1, 1).copy()
+    ukf = UnscentedKalmanFilter(H=np.diag([1, 1, 0, 0]), Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
+    dt1 = generate_dts(st.dts[:4], 2)
+    dt2 = generate_dts(st.dts[4:], 2)
+    with NoisePatch("zero"):
+        m1, c1 = ukf.run(nsteps=len(dt1), dt=dt1, ship_track=st)
+        m2, c2 = ukf.run(nsteps=len(dt2), dt=dt2, ship_track=st)
+    return dict(dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0], cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0],
+                dt1=dt1, dt2=dt2, means1=m1, covs1=c1, means2=m2, covs2=c2, time_end=np.float64(ukf.time), Q=Q, R=R, P0=P)
+
+
 def csv_fixture():
     """Rows of ship 01203823 cut from the reference's data file (the input of its own CLI example), plus one of the
     header rows the source file repeats between ships, so the id column stays a string column as in the full file."""
@@ -416,6 +434,7 @@ def main():
     csv_fixture()
     np.savez_compressed(os.path.join(HERE, "gp.npz"), **gp_cases())
     np.savez_compressed(os.path.join(HERE, "modern_ships.npz"), **modern_cases())
+    np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

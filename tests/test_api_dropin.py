@@ -141,3 +141,22 @@ def test_geodetic_dynamics_function():
     # 2-entry state: the reference truncates the result to x.shape[0] and needs c to supply speed/heading
     y2 = geodetic_dynamics(k["gd_x"][0][:2], k["gd_x"][0][2:], k["gd_dt"][0], k["gd_sr"][0], k["gd_cr"][0])
     np.testing.assert_allclose(y2, k["gd_y"][0][:2], rtol=1e-13)
+
+
+def test_second_run_appends_and_keeps_time():
+    """Like the reference, a second ``run`` on the same object appends to the history, restarts the update index at 0
+    and keeps accumulating ``self.time`` (so its float-equality trigger sees offset times)."""
+    from track_estimators.kalman_filters.non_linear_process import geodetic_dynamics
+    from track_estimators.kalman_filters.unscented import UnscentedKalmanFilter
+
+    g = np.load(os.path.join(GOLDEN, "two_runs.npz"))
+    st = _ship_track({k: g[k] for k in ("z", "dts", "sog", "cog", "sog_rate", "cog_rate")})
+    ukf = UnscentedKalmanFilter(H=np.diag([1, 1, 0, 0]), Q=g["Q"], R=g["R"], P=g["P0"],
+                                x0=st.z[:, 0].reshape(-1, 1).copy(), non_linear_process=geodetic_dynamics)
+    ukf.inject_noise = False
+    m1, c1 = ukf.run(nsteps=len(g["dt1"]), dt=g["dt1"], ship_track=st)
+    assert mean_err(m1, g["means1"]) < 1e-9 and cov_err(c1, g["covs1"]) < 1e-9
+    m2, c2 = ukf.run(nsteps=len(g["dt2"]), dt=g["dt2"], ship_track=st)
+    assert m2.shape == g["means2"].shape == (len(g["dt1"]) + len(g["dt2"]) + 2, 4)
+    assert mean_err(m2, g["means2"]) < 1e-9 and cov_err(c2, g["covs2"]) < 1e-9
+    assert ukf.time == float(g["time_end"])
