@@ -41,14 +41,14 @@ TRAFFIC_BWD = 337 + 560  # urtss_gain_kernel + urtss_combine_l1
 FLOPS_PER_TRACK_STEP = 2.0e4  # SURVEY.md §8d estimate (fp64 flop-equivalents, forward + backward)
 
 
-def cpu_baseline(ntracks: int):
+def cpu_baseline(ntracks: int, seed0: int = 0):
     """Time the oracle's vectorised restatement on `ntracks` tracks of the same workload (single process)."""
     from track_estimators import batch, synthetic
 
     from oracle import ukf_oracle as orc
 
     H, Q, R, P0 = synthetic.example_matrices()
-    sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=0)
+    sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=seed0)
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     fires = hb.upd_idx.T >= 0
     zidx = np.where(fires, hb.upd_idx.T, 0)
@@ -59,6 +59,39 @@ def cpu_baseline(ntracks: int):
     sm, sP = orc.backward_batch(m, P, Q, hb.dt.T, rr, sb.sog_rate, sb.cog_rate)
     dt = time.perf_counter() - t0
     return hb.track_steps / dt, dt, (m, P, sm, sP), hb
+
+
+def _pool_worker(job):
+    seed0, ntracks = job
+    v, secs, _, hb = cpu_baseline(ntracks, seed0=seed0)
+    return hb.track_steps, secs
+
+
+def host_core_share() -> int:
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one, and by 16 --
+    the CPU share of a one-GPU box -- when the quota is not visible."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
+def cpu_baseline_pool(procs: int, tracks_per_proc: int):
+    """The same oracle on every host core this process may use: `procs` forked workers, each timing its own
+    `tracks_per_proc`-track sample (SURVEY.md §8d asks for the single-process and the all-cores figure).  Must run
+    before anything initialises the GPU (fork after HIP init is not safe)."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_pool_worker, [(10_000_000 + i * tracks_per_proc, tracks_per_proc) for i in range(procs)])
+    steps = sum(r[0] for r in res)
+    secs = max(r[1] for r in res)
+    return steps / secs, secs
 
 
 def main():
@@ -72,15 +105,23 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather even with one rank (rehearsal of the N>1 path)")
+    ap.add_argument("--cpu-pool-tracks", type=int, default=768,
+                    help="tracks per worker in the all-cores CPU-baseline leg (0 = skip)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    pool_result = None
+    if world == 1 and args.gpus == 1 and args.cpu_tracks > 0 and args.cpu_pool_tracks > 0:
+        # all-cores leg of the CPU baseline: forked workers, so it runs before this process touches the GPU
+        procs = host_core_share()
+        pool_result = (procs,) + cpu_baseline_pool(procs, args.cpu_pool_tracks)
 
     import torch
 
     from track_estimators import batch, distributed, synthetic
     from track_estimators._hip import binding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
@@ -229,6 +270,11 @@ def main():
                 "host_cpus": os.cpu_count(),
                 "gpu_vs_oracle_max_rel_err_smoothed_means": err,
             }
+            if pool_result is not None:
+                out["cpu_baseline"]["all_cores"] = {
+                    "value": pool_result[1], "unit": "track-steps/s", "cores": pool_result[0],
+                    "sample": f"{pool_result[0]} forked workers x {args.cpu_pool_tracks} tracks x {chb.Nmax} steps "
+                              f"({pool_result[2]:.1f} s, slowest worker)"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

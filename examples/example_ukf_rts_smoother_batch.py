@@ -38,14 +38,13 @@ def main():
     P = np.diag([1.0, 1.0, 1.0, 1.0])
 
     t0 = time.perf_counter()
-    tracks, dts, x0s, kept = [], [], [], []
+    tracks, dts, kept = [], [], []
     for sid in ids:
         try:
             st = ShipTrack()
             st.read_csv(csv_file=csv, ship_id=sid, id_col="primary.id", lat_col="lat", lon_col="lon2", reverse=False)
-            z = st.get_measurements(include_sog=True, include_cog=True)
-            st.calculate_cog_rate()
-            st.calculate_sog_rate()
+            if len(st.lon) < 2:
+                raise IndexError("fewer than 2 observations")
         except Exception as exc:  # a ship whose rows cannot be parsed does not stop the batch
             print("Error in ", sid, type(exc).__name__)
             continue
@@ -55,8 +54,10 @@ def main():
             continue
         tracks.append(st)
         dts.append(dt_array)
-        x0s.append(z[:, 0].copy())
         kept.append(sid)
+    # sog / cog / rates / z of every kept ship in one launch (the reference: get_measurements + calculate_*_rate per ship)
+    batch.prepare_ship_tracks(tracks)
+    x0s = [st.z[:, 0].copy() for st in tracks]
     t1 = time.perf_counter()
     noise = [batch.draw_reference_noise(Q, R, d, st.dts) for d, st in zip(dts, tracks)]  # what the reference injects
     hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P, noise=noise)

@@ -14,6 +14,8 @@
  *   ste_ukf_update_f64       UnscentedKalmanFilter.update  (one step, many filters)   unscented.py:209-265
  *   ste_geodetic_dynamics_f64  geodetic_dynamics              kalman_filters/non_linear_process.py:6-85
  *   ste_sigma_points_f64     UnscentedKalmanFilter.compute_sigma_points  unscented.py:76-107
+ *   ste_track_prep_f64       ShipTrack.calculate_sog / _cog / _sog_rate / _cog_rate / get_measurements
+ *                            src/track_estimators/ship_track.py:197-338 (distance / heading: utils.py:9-147)
  *
  * Conventions
  *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void* (NULL = default stream).
@@ -238,6 +240,39 @@ int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream);
  */
 int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m, const double* xs, double* Kstar,
                        double* mean, double* var, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Observation preparation: speed / course over ground and their rates for a batch of tracks, the
+ * device counterpart of ShipTrack.calculate_sog (ship_track.py:197-224), calculate_sog_rate (:226-250),
+ * calculate_cog (:252-278), calculate_cog_rate (:280-304) and get_measurements(include_sog=True, include_cog=True)
+ * (:306-338).  Arrays are [Tmax][B], track index fastest; observation i >= nobs[t] of a short track is written as 0.
+ *   sog[i]      = distance(i, i+1) / gap[i]   (km/h), last value repeated;  gap = 0 gives inf / NaN as in the reference
+ *   cog[i]      = heading(i, i+1)             (degrees in [0, 360)), last value repeated
+ *   *_rate[i]   = (v[i] - v[i-1]) / gap[i-1], 0 for i = 0
+ *   z[i][0..3]  = lon, lat, sog, cog          (optional; the layout ste_ukf_batch_f64.z consumes)
+ * A track with fewer than 2 observations has no leg: all outputs 0 (the reference raises IndexError there).
+ * ------------------------------------------------------------------------------------------------------------- */
+#define STE_PREP_SPHERE 0 /* haversine_formula + heading on the 6378.137 km sphere (utils.py:75-147) */
+#define STE_PREP_WGS84 1  /* geographiclib_distance + geographiclib_heading semantics (utils.py:9-72), WGS84 inverse
+                             geodesic by Vincenty's iteration */
+
+typedef struct ste_prep_batch_f64 {
+    int32_t B;            /* tracks */
+    int32_t Tmax;         /* observations per track (padded) */
+    int32_t model;        /* STE_PREP_* */
+    int32_t reserved;
+    const int32_t* nobs;  /* [B] observations per track, NULL = Tmax for all */
+    const double* lon;    /* [Tmax][B] degrees */
+    const double* lat;    /* [Tmax][B] degrees */
+    const double* gap;    /* [Tmax-1][B] hours between observation i and i+1 (ShipTrack.dts) */
+    double* sog;          /* [Tmax][B] out */
+    double* cog;          /* [Tmax][B] out */
+    double* sog_rate;     /* [Tmax][B] out */
+    double* cog_rate;     /* [Tmax][B] out */
+    double* z;            /* [Tmax][4][B] out, may be NULL */
+} ste_prep_batch_f64;
+
+int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream);
 
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "../../include/ste.h"
+#include "ste_err.h"
 #include "ste_math.h"
 #include "ste_quad.h"
 
@@ -1234,6 +1235,13 @@ int check_hip(hipError_t e, const char* what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return STE_ELAUNCH;
 }
+}  // namespace
+
+// ste_err.h: the same error string for the other translation units of this ABI (ste_prep.hip)
+int ste::abi_fail(int code, const char* msg) { return fail(code, "%s", msg); }
+int ste::abi_check_hip(hipError_t e, const char* what) { return check_hip(e, what); }
+
+namespace {
 
 int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, ste::KParams* kp) {
     if (!b) return fail(STE_EINVAL, "batch pointer is NULL");

@@ -92,6 +92,29 @@ class SteGpBatchF64(C.Structure):
     ]
 
 
+class StePrepBatchF64(C.Structure):
+    """Mirror of ``struct ste_prep_batch_f64`` (include/ste.h)."""
+
+    _fields_ = [
+        ("B", C.c_int32),
+        ("Tmax", C.c_int32),
+        ("model", C.c_int32),
+        ("reserved", C.c_int32),
+        ("nobs", _dp),
+        ("lon", _dp),
+        ("lat", _dp),
+        ("gap", _dp),
+        ("sog", _dp),
+        ("cog", _dp),
+        ("sog_rate", _dp),
+        ("cog_rate", _dp),
+        ("z", _dp),
+    ]
+
+
+STE_PREP_SPHERE = 0
+STE_PREP_WGS84 = 1
+
 # every symbol include/ste.h declares: (restype, argtypes)
 SYMBOLS = {
     "ste_version": (C.c_int, []),
@@ -107,6 +130,7 @@ SYMBOLS = {
     "ste_ukf_robust_terms_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_sigma_points_f64": (C.c_int, [C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
     "ste_sigma_points_generic_f64": (C.c_int, [C.c_int32, C.c_int64, _dp, _dp, C.c_double, _dp, C.c_void_p]),
+    "ste_track_prep_f64": (C.c_int, [C.POINTER(StePrepBatchF64), C.c_void_p]),
     "ste_gp_last_error": (C.c_char_p, []),
     "ste_gp_rbf_kmatrix_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
     "ste_gp_potrf_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),

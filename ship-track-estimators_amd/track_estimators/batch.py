@@ -358,6 +358,84 @@ class DeviceBatch:
         return self.status.cpu().numpy()
 
 
+def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: str = "wgs84", device="cuda:0"):
+    """Speed / course over ground and their rates for many tracks in one launch (``ste_track_prep_f64``).
+
+    ``lons[b]``, ``lats[b]`` (length T_b, degrees) and ``gaps[b]`` (length T_b - 1, hours) are what ``ShipTrack.read_csv``
+    returns.  ``model`` is ``"wgs84"`` (the ShipTrack defaults, geographiclib_distance / _heading) or ``"sphere"``
+    (haversine_formula / heading).  Returns one dict per track with ``sog, cog, sog_rate, cog_rate`` (length T_b) and
+    ``z`` (4, T_b) = the result of ``get_measurements(include_sog=True, include_cog=True)`` (ship_track.py:197-338).
+    """
+    import torch
+
+    lib = binding.require_gpu()
+    models = {"sphere": binding.STE_PREP_SPHERE, "wgs84": binding.STE_PREP_WGS84}
+    if model not in models:
+        raise ValueError(f"model must be one of {sorted(models)}, got {model!r}")
+    B = len(lons)
+    if B == 0:
+        return []
+    nobs = np.asarray([len(v) for v in lons], dtype=np.int32)
+    for b in range(B):
+        if len(lats[b]) != nobs[b] or len(gaps[b]) != nobs[b] - 1:
+            raise ValueError(f"track {b}: need len(lat) == len(lon) and len(gaps) == len(lon) - 1")
+        if nobs[b] < 2:
+            raise IndexError(f"track {b} has fewer than 2 observations (ship_track.py:220 indexes sog[-1])")
+    T = int(nobs.max())
+    lon = np.zeros((T, B))
+    lat = np.zeros((T, B))
+    gap = np.ones((max(T - 1, 1), B))
+    for b in range(B):
+        lon[: nobs[b], b] = lons[b]
+        lat[: nobs[b], b] = lats[b]
+        gap[: nobs[b] - 1, b] = gaps[b]
+    dev = torch.device(device)
+    up = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    t_n, t_lon, t_lat, t_gap = up(nobs), up(lon), up(lat), up(gap)
+    outs = torch.empty((4, T, B), dtype=torch.float64, device=dev)
+    z = torch.empty((T, 4, B), dtype=torch.float64, device=dev)
+    s = binding.StePrepBatchF64()
+    s.B, s.Tmax, s.model = B, T, models[model]
+    s.nobs, s.lon, s.lat, s.gap = t_n.data_ptr(), t_lon.data_ptr(), t_lat.data_ptr(), t_gap.data_ptr()
+    s.sog, s.cog, s.sog_rate, s.cog_rate = (outs[i].data_ptr() for i in range(4))
+    s.z = z.data_ptr()
+    stream = torch.cuda.current_stream(dev)
+    binding.check(lib.ste_track_prep_f64(C.byref(s), C.c_void_p(stream.cuda_stream)), "ste_track_prep_f64")
+    h = outs.cpu().numpy()
+    zh = z.cpu().numpy()
+    res = []
+    for b in range(B):
+        n = nobs[b]
+        res.append({"sog": h[0, :n, b].copy(), "cog": h[1, :n, b].copy(), "sog_rate": h[2, :n, b].copy(),
+                    "cog_rate": h[3, :n, b].copy(), "z": np.ascontiguousarray(zh[:n, :, b].T)})
+    return res
+
+
+def prepare_ship_tracks(ship_tracks: Sequence, device="cuda:0"):
+    """Fill ``sog, cog, sog_rate, cog_rate, z`` of every ShipTrack (already ``read_csv``'d) in one launch -- what the
+    reference does per ship with calculate_cog / calculate_sog / calculate_*_rate / get_measurements(True, True)
+    (examples/example_ukf_rts_smoother_batch.py:33-40).  The distance / heading pair configured on each ShipTrack
+    selects the model; anything but the two pairs the reference ships raises."""
+    from . import utils
+
+    pairs = {(utils.geographiclib_distance, utils.geographiclib_heading): "wgs84",
+             (utils.haversine_formula, utils.heading): "sphere"}
+    groups = {}
+    for i, st in enumerate(ship_tracks):
+        key = pairs.get((st.calc_distance_func, st.calc_heading_func))
+        if key is None:
+            raise ValueError("prepare_ship_tracks supports the (geographiclib_distance, geographiclib_heading) and "
+                             "(haversine_formula, heading) pairs only; call ShipTrack.calculate_* for custom functions")
+        groups.setdefault(key, []).append(i)
+    for model, idx in groups.items():
+        res = prepare_observations([ship_tracks[i].lon for i in idx], [ship_tracks[i].lat for i in idx],
+                                   [ship_tracks[i].dts for i in idx], model=model, device=device)
+        for i, r in zip(idx, res):
+            st = ship_tracks[i]
+            st.sog, st.cog, st.sog_rate, st.cog_rate, st.z = r["sog"], r["cog"], r["sog_rate"], r["cog_rate"], r["z"]
+    return ship_tracks
+
+
 def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True):
     """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays."""
     db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains)

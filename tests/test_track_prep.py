@@ -1,0 +1,133 @@
+"""
+Observation preparation on the device (ste_track_prep_f64) against the host ShipTrack methods, which restate the
+reference's calculate_sog / calculate_cog / calculate_*_rate / get_measurements (ship_track.py:197-338).
+
+Floating-point tolerance: the device evaluates the same formulas with its own libm and contracted FMAs; distances and
+headings agree to ~1e-13 relative, and the rates -- differences of neighbouring values divided by the gap -- to 1e-9
+absolute at the magnitudes of these tracks.  Non-finite values (duplicate timestamps, gap = 0) must match exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from track_estimators import batch
+from track_estimators.ship_track import ShipTrack
+from track_estimators.utils import generate_dts, haversine_formula, heading
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FUNCS = {"sphere": dict(calc_distance_func=haversine_formula, calc_heading_func=heading), "wgs84": {}}
+
+
+def host_track(lon, lat, dts, model):
+    st = ShipTrack(**FUNCS[model])
+    st.lon, st.lat, st.dts = np.asarray(lon, float), np.asarray(lat, float), np.asarray(dts, float)
+    with np.errstate(all="ignore"):
+        st.calculate_cog()
+        st.calculate_sog()
+        st.calculate_sog_rate()
+        st.calculate_cog_rate()
+        st.get_measurements(include_sog=True, include_cog=True)
+    return st
+
+
+def random_tracks(rng, B, tmin, tmax):
+    out = []
+    for _ in range(B):
+        T = int(rng.integers(tmin, tmax + 1))
+        lon = rng.uniform(-170, 170) + np.cumsum(rng.normal(0, 0.3, T))
+        lat = rng.uniform(-60, 60) + np.cumsum(rng.normal(0, 0.2, T))
+        dts = rng.choice([0.5, 1.0, 6.0, 23.0, 24.0, 25.0], T - 1)
+        out.append((lon, lat, dts))
+    return out
+
+
+def compare(res, st, rate_atol=1e-9):
+    np.testing.assert_allclose(res["sog"], st.sog, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["cog"], st.cog, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(res["sog_rate"], st.sog_rate, rtol=1e-8, atol=rate_atol)
+    np.testing.assert_allclose(res["cog_rate"], st.cog_rate, rtol=1e-8, atol=rate_atol)
+    np.testing.assert_allclose(res["z"], st.z, rtol=1e-10, atol=1e-10)
+    assert res["z"].shape == st.z.shape
+
+
+@pytest.mark.parametrize("model", ["sphere", "wgs84"])
+def test_prep_ragged_random(model):
+    tracks = random_tracks(np.random.default_rng(11), 37, 2, 90)
+    res = batch.prepare_observations([t[0] for t in tracks], [t[1] for t in tracks], [t[2] for t in tracks], model=model)
+    assert len(res) == len(tracks)
+    for r, (lon, lat, dts) in zip(res, tracks):
+        compare(r, host_track(lon, lat, dts, model))
+
+
+def test_prep_reference_fixture_row0():
+    # the reference's CLI example output pins the WGS84 path: first row of output_01203823_predictions.txt
+    st = ShipTrack()
+    st.read_csv(os.path.join(GOLDEN, "ship_01203823.csv"), ship_id="01203823", id_col="primary.id", lat_col="lat", lon_col="lon")
+    batch.prepare_ship_tracks([st])
+    np.testing.assert_allclose(st.z[:, 0], [-30.5, -0.5, 14.578418614021368, 198.52495095065817], rtol=1e-11)
+    host = host_track(st.lon, st.lat, st.dts, "wgs84")
+    compare({"sog": st.sog, "cog": st.cog, "sog_rate": st.sog_rate, "cog_rate": st.cog_rate, "z": st.z}, host)
+
+
+@pytest.mark.parametrize("model", ["sphere", "wgs84"])
+def test_prep_duplicate_timestamps_and_coincident_points(model):
+    # gap = 0 -> distance / 0 (ship_track.py:217): inf for a moved ship, NaN for a stationary one, and the rates
+    # built on them; data/modern_ships has thousands of these
+    lon = np.array([10.0, 10.2, 10.2, 10.5, 10.5, 10.9, 11.0])
+    lat = np.array([50.0, 50.1, 50.1, 50.3, 50.3, 50.2, 50.2])
+    dts = np.array([1.0, 0.0, 2.0, 1.0, 0.0, 1.0])
+    lon[4] = 10.6  # moved within a zero gap -> inf
+    r = batch.prepare_observations([lon], [lat], [dts], model=model)[0]
+    st = host_track(lon, lat, dts, model)
+    for k in ("sog", "cog", "sog_rate", "cog_rate"):
+        a, b = r[k], getattr(st, k)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b), err_msg=k)
+        np.testing.assert_array_equal(np.isposinf(a), np.isposinf(b), err_msg=k)
+        np.testing.assert_array_equal(np.isneginf(a), np.isneginf(b), err_msg=k)
+        ok = np.isfinite(b)
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert np.isnan(st.sog).any() and np.isinf(st.sog).any()
+
+
+def test_prep_rejects_bad_input():
+    with pytest.raises(IndexError):
+        batch.prepare_observations([[1.0]], [[2.0]], [[]])
+    with pytest.raises(ValueError):
+        batch.prepare_observations([[1.0, 2.0]], [[2.0, 3.0]], [[1.0]], model="flat-earth")
+    st = ShipTrack(calc_distance_func=lambda *a: 0.0)
+    st.lon, st.lat, st.dts = np.zeros(3), np.zeros(3), np.ones(2)
+    with pytest.raises(ValueError):
+        batch.prepare_ship_tracks([st])
+
+
+def test_prep_feeds_filter_end_to_end():
+    # raw positions -> device preparation -> batched UKF + URTSS, against the same run on host-prepared tracks
+    H, Q, R = np.diag([1.0, 1, 0, 0]), np.diag([1e-4, 1e-4, 1e-6, 1e-6]), np.diag([0.25, 0.25, 0, 0])
+    P0 = np.eye(4)
+    rng = np.random.default_rng(5)
+    tracks = []
+    for _ in range(12):  # steady ships: ~20 km/h on a slowly turning course, positions jittered by 0.01 deg
+        T = int(rng.integers(20, 60))
+        dts = rng.choice([1.0, 2.0, 6.0], T - 1)
+        course = np.radians(rng.uniform(0, 360) + np.cumsum(rng.normal(0, 2.0, T - 1)))
+        lat = rng.uniform(-50, 50) + np.concatenate([[0], np.cumsum(0.18 * dts * np.cos(course))])
+        lon = rng.uniform(-150, 150) + np.concatenate([[0], np.cumsum(0.18 * dts * np.sin(course))])
+        tracks.append((lon + rng.normal(0, 0.01, T), lat + rng.normal(0, 0.01, T), dts))
+    host = [host_track(*t, "wgs84") for t in tracks]
+    dev = []
+    for lon, lat, dts in tracks:
+        st = ShipTrack()
+        st.lon, st.lat, st.dts = lon, lat, dts
+        dev.append(st)
+    batch.prepare_ship_tracks(dev)
+    outs = []
+    for sts in (host, dev):
+        hb = batch.pack_tracks(sts, [generate_dts(st.dts, 2) for st in sts], [st.z[:, 0] for st in sts], H, Q, R, P0)
+        outs.append(batch.run_batch(hb))
+    assert not outs[0]["status"].any() and not outs[1]["status"].any()
+    for b, st in enumerate(host):
+        n = outs[0]["nsteps"][b] + 1
+        a, c = outs[0]["means_smoothed"][b, :n], outs[1]["means_smoothed"][b, :n]
+        assert np.max(np.abs(a - c) / np.maximum(np.abs(a), 1e-12)) < 1e-6
