@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--nobs", type=int, default=2000)
     ap.add_argument("--evals", type=int, default=3)
     ap.add_argument("--cpu-evals", type=int, default=2)
+    ap.add_argument("--fit", action="store_true",
+                    help="also time a full hyper-parameter fit of every track (lock-step batched L-BFGS-B, no restarts) "
+                         "beside scikit-learn's fit of one track on the host (SURVEY.md §8d config 5 (iii))")
     args = ap.parse_args()
 
     import torch
@@ -71,6 +74,38 @@ def main():
                                "sample": f"{args.cpu_evals} objective evaluations at n={n} (oracle/gp_oracle.py: SciPy "
                                          "LAPACK cholesky/cho_solve, the same calls scikit-learn makes), BLAS threads = all",
                                "gpu_vs_oracle_rel_err_lml": float(abs(lml[args.cpu_evals - 1] - l) / abs(l))}
+    if args.fit:
+        from track_estimators.gaussian_processes import gaussian_process as gpm
+
+        theta0 = np.log([1.0, 1.0, 0.5])  # 1.0 * RBF(1.0) + WhiteKernel(0.5), the reference example's kernel
+        bounds = np.log(np.tile([1e-5, 1e5], (3, 1)))
+        calls = [0]
+        plain = batch.objective
+
+        def counted(*a, **k):
+            calls[0] += 1
+            return plain(*a, **k)
+
+        batch.objective = counted
+        t0 = time.perf_counter()
+        th, best = gpm.fit_thetas(batch, theta0, bounds, 0, None)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+        batch.objective = plain
+        out["fit"] = {"seconds": t_fit, "tracks": B, "tracks_per_s": B / t_fit, "batched_objective_launches": calls[0],
+                      "theta_median": np.exp(np.median(th, axis=0)).tolist()}
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+
+        t0 = time.perf_counter()
+        ref = GaussianProcessRegressor(kernel=1.0 * RBF(1.0) + WhiteKernel(0.5)).fit(xs[0].reshape(-1, 1), ys[0])
+        t_ref = time.perf_counter() - t0
+        out["fit"]["cpu_reference"] = {
+            "seconds_per_track": t_ref, "cores": os.cpu_count(), "kind": "reference",
+            "sample": "scikit-learn GaussianProcessRegressor.fit on track 0, the call the reference's GPRegression.fit "
+                      "makes (gaussian_process.py:63-66)",
+            "lml_rel_diff_track0": float(abs(best[0] - ref.log_marginal_likelihood_value_)
+                                         / abs(ref.log_marginal_likelihood_value_))}
     print(json.dumps(out))
 
 

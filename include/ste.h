@@ -233,6 +233,12 @@ int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream);
  */
 int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream);
 
+/* The same evaluation for `count` of the batch's matrices only: active[count] (DEVICE int32, distinct indices in
+ * [0, B)) names them.  Outputs of the other matrices are left untouched.  This is what a lock-step batched optimiser
+ * uses once some of its tracks have converged (scipy's L-BFGS-B stops per track, gaussian_process.py:63-66 via
+ * scikit-learn's _constrained_optimization); per-matrix results do not depend on which other matrices are listed. */
+int ste_gp_lml_subset_f64(const ste_gp_batch_f64* b, int32_t count, const int32_t* active, void* stream);
+
 /*
  * Posterior mean [B][nout][mmax] and variance [B][mmax] at m[b] new inputs xs [B][mmax]
  * (GaussianProcessRegressor.predict(return_std=True); std = sqrt(max(var, 0)) is left to the caller).

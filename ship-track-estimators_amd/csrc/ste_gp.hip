@@ -50,7 +50,13 @@ struct GpParams {
     double* tr;     // [B][3][ntiles_max] per-tile partial sums of tr(K^-1 Krbf), tr(K^-1 (Krbf o D2)), tr(K^-1)
     int32_t* status;
     int store_kinv;
+    // Subset launches (ste_gp_lml_subset_f64): the grid covers `nslots` matrices and slot s works on matrix active[s];
+    // without a list, slot s is matrix s and nslots == B.
+    int nslots;
+    const int32_t* active;
 };
+
+__device__ __forceinline__ int matrix_of(const GpParams& p, int slot) { return p.active ? p.active[slot] : slot; }
 
 __device__ __forceinline__ int nblocks(int n) { return (n + T - 1) / T; }
 
@@ -115,7 +121,7 @@ __device__ __forceinline__ void for_each_acc(v4d (&acc)[2][2], int wave, int lan
 // K build: lower tiles of K (including the diagonal tiles in full), identity on the padding.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gp_kbuild(const GpParams p) {
-    const int b = blockIdx.y;
+    const int b = matrix_of(p, blockIdx.y);
     const int n = p.n[b];
     const int nb = nblocks(n);
     // tile index -> (ti >= tj)
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void gp_potrf(const GpParams p) {
     __shared__ double S[T * LD];
     __shared__ double X[T * LD];
     __shared__ int ok;
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = matrix_of(p, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = nblocks(p.n[b]);
     const size_t ld = p.ld;
     double* K = p.K + (size_t)b * ld * ld;
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void gp_potrf(const GpParams p) {
 template <bool kPerMatrix>
 __global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
     __shared__ double S[T * LD];
-    const int b = kPerMatrix ? blockIdx.x : blockIdx.y;
+    const int b = matrix_of(p, kPerMatrix ? blockIdx.x : blockIdx.y);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = nblocks(p.n[b]);
     const int a_begin = kPerMatrix ? 0 : blockIdx.x, a_end = kPerMatrix ? nb : blockIdx.x + 1;
@@ -366,8 +372,9 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
     const int nb2_max = (p.nb_max + 1) / 2;
     const int ntile_grid = nb2_max * (nb2_max + 1) / 2;
     const int id = blockIdx.x, slot = id >> 3;
-    const int b = (slot / ntile_grid) * 8 + (id & 7);
-    if (b >= p.B) return;
+    const int bslot = (slot / ntile_grid) * 8 + (id & 7);
+    if (bslot >= p.nslots) return;
+    const int b = matrix_of(p, bslot);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n), nb2 = (nb + 1) / 2;
     int tile = slot % ntile_grid;
@@ -449,7 +456,7 @@ __device__ __forceinline__ double* gp_wbuf(const GpParams& p, int b) { return p.
 __device__ __forceinline__ double* gp_share(const GpParams& p, int b) { return gp_wbuf(p, b) + (size_t)p.nout * p.ld; }
 
 __global__ __launch_bounds__(64) void gp_w(const GpParams p) {
-    const int b = blockIdx.y, kb = blockIdx.x, lane = threadIdx.x;
+    const int b = matrix_of(p, blockIdx.y), kb = blockIdx.x, lane = threadIdx.x;
     const int n = p.n[b], nb = nblocks(n);
     if (kb >= nb) return;
     const size_t ld = p.ld;
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(64) void gp_w(const GpParams p) {
 
 __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
     __shared__ double red[5][4];
-    const int b = blockIdx.y, ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = matrix_of(p, blockIdx.y), ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n), npad = nb * T;
     if (ab >= nb) return;
     const size_t ld = p.ld;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
 // spread over nb workgroups per matrix).
 __global__ __launch_bounds__(256) void gp_quad(const GpParams p) {
     __shared__ double red[2][4];
-    const int b = blockIdx.y, ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = matrix_of(p, blockIdx.y), ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n);
     if (ab >= nb) return;
     const double* x = p.x + (size_t)b * p.nmax;
@@ -557,8 +564,9 @@ __global__ __launch_bounds__(256) void gp_quad(const GpParams p) {
 }
 
 __global__ __launch_bounds__(64) void gp_finish(const GpParams p) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= p.B) return;
+    const int bslot = blockIdx.x * 64 + threadIdx.x;
+    if (bslot >= p.nslots) return;
+    const int b = matrix_of(p, bslot);
     const int n = p.n[b], nb = nblocks(n), nout = p.nout;
     const double* sh = gp_share(p, b);
     double r[5] = {0, 0, 0, 0, 0};
@@ -718,6 +726,8 @@ int gp_params(const ste_gp_batch_f64* b, stegp::GpParams* p) {
     p->tr = b->tr;
     p->status = b->status;
     p->store_kinv = 0;
+    p->nslots = b->B;
+    p->active = nullptr;
     return STE_OK;
 }
 }  // namespace
@@ -743,28 +753,42 @@ int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream) {
     return gp_hip(hipGetLastError(), "gp_potrf launch");
 }
 
-int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) {
+static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t* active, void* stream) {
     stegp::GpParams p;
     int rc = gp_params(b, &p);
     if (rc) return rc;
+    if (active) {
+        if (count < 0 || count > p.B) return gp_fail("count must be in 0..B");
+        if (count == 0) return STE_OK;
+        p.nslots = count;
+        p.active = active;
+    }
+    const unsigned ns = (unsigned)p.nslots;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
-    hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, s, p);
-    if (p.B >= 128)
-        hipLaunchKernelGGL(stegp::gp_trtri<true>, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, ns), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_potrf, dim3(ns), dim3(256), 0, s, p);
+    if (ns >= 128)
+        hipLaunchKernelGGL(stegp::gp_trtri<true>, dim3(ns), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) {
-        const unsigned groups = (unsigned)((p.B + 7) / 8);
+        const unsigned groups = (ns + 7) / 8;
         const unsigned nb2 = (unsigned)((p.nb_max + 1) / 2), tiles128 = nb2 * (nb2 + 1) / 2;
         hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * tiles128), dim3(256), 0, s, p, b->Kinv);
     }
-    hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, p.B), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
-    if (p.grad) hipLaunchKernelGGL(stegp::gp_quad, dim3(p.nb_max, p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_finish, dim3((p.B + 63) / 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, ns), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, ns), dim3(256), 0, s, p);
+    if (p.grad) hipLaunchKernelGGL(stegp::gp_quad, dim3(p.nb_max, ns), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_finish, dim3((ns + 63) / 64), dim3(64), 0, s, p);
     return gp_hip(hipGetLastError(), "gp_lml launch");
+}
+
+int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream) { return gp_lml_launch(b, 0, nullptr, stream); }
+
+int ste_gp_lml_subset_f64(const ste_gp_batch_f64* b, int32_t count, const int32_t* active, void* stream) {
+    if (!active) return gp_fail("active (device int32[count]) is required; use ste_gp_lml_f64 for the whole batch");
+    return gp_lml_launch(b, count, active, stream);
 }
 
 int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m, const double* xs, double* Kstar,

@@ -135,6 +135,7 @@ SYMBOLS = {
     "ste_gp_rbf_kmatrix_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
     "ste_gp_potrf_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
     "ste_gp_lml_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
+    "ste_gp_lml_subset_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, C.c_void_p]),
     "ste_gp_predict_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
 }

@@ -71,8 +71,11 @@ class GpDeviceBatch:
         th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(self.B, 3))
         self.t_theta.copy_(self.torch.from_numpy(th))
 
-    def objective(self, thetas, eval_gradient: bool = True, keep_kinv: bool = False):
-        """(lml[B], grad[B,3] or None, status[B]) at thetas[B,3] = log(constant, length_scale, noise)."""
+    def objective(self, thetas, eval_gradient: bool = True, keep_kinv: bool = False, active=None):
+        """(lml[B], grad[B,3] or None, status[B]) at thetas[B,3] = log(constant, length_scale, noise).
+
+        ``active``: optional sequence of track indices; only those are evaluated (``ste_gp_lml_subset_f64``) and the
+        entries of the other tracks in the returned arrays are whatever their last evaluation left."""
         self._set_theta(thetas)
         s = self.struct
         s.grad = self.t_grad.data_ptr() if eval_gradient else None
@@ -82,7 +85,15 @@ class GpDeviceBatch:
             s.Kinv = self.t_Kinv.data_ptr()
         else:
             s.Kinv = None
-        binding.check(self.lib.ste_gp_lml_f64(C.byref(s), self._stream()), "ste_gp_lml_f64")
+        if active is None:
+            binding.check(self.lib.ste_gp_lml_f64(C.byref(s), self._stream()), "ste_gp_lml_f64")
+        else:
+            idx = np.unique(np.asarray(list(active), dtype=np.int32))
+            if len(idx) and (idx[0] < 0 or idx[-1] >= self.B):
+                raise IndexError("active track index out of range")
+            t_idx = self.torch.from_numpy(idx).to(self.device)
+            binding.check(self.lib.ste_gp_lml_subset_f64(C.byref(s), len(idx), t_idx.data_ptr(), self._stream()),
+                          "ste_gp_lml_subset_f64")
         lml = self.t_lml.cpu().numpy()
         grad = self.t_grad.cpu().numpy() if eval_gradient else None
         status = self.t_status.cpu().numpy()

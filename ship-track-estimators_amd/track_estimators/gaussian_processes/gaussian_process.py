@@ -64,7 +64,9 @@ class _LockstepObjective:
 
     def _launch_if_ready(self):
         if self.active and self.pending >= self.active:
-            lml, grad, _ = self.batch.objective(self.theta, eval_gradient=True)
+            # only the tracks whose optimiser is still running are evaluated; the converged ones drop out of the launch
+            subset = None if len(self.active) == self.batch.B else sorted(self.active)
+            lml, grad, _ = self.batch.objective(self.theta, eval_gradient=True, active=subset)
             self.results = (lml, grad)
             self.pending.clear()
             self.generation += 1

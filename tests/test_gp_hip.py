@@ -118,3 +118,26 @@ def test_fit_batch_lockstep_matches_single_fits():
         np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-9, atol=1e-9)
     preds = gp.predict_batch([g[f"{n}_tq"] for n in NAMES])
     assert all(p[0].shape == (len(g[f"{n}_tq"]), 2) for p, n in zip(preds, NAMES))
+
+
+def test_subset_evaluation_matches_full_batch_and_leaves_others_alone():
+    """ste_gp_lml_subset_f64: listed tracks get the bits a full launch gives them, the others keep their last outputs."""
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    data = [_data(g, n) for n in NAMES] * 2  # six tracks, ragged
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data])
+    th_a, th_b = g["thetas"][0], g["thetas"][2]
+    full_a = batch.objective(np.tile(th_a, (6, 1)))
+    full_b = batch.objective(np.tile(th_b, (6, 1)))
+    batch.objective(np.tile(th_a, (6, 1)))  # device outputs now hold the theta_a results
+    theta = np.tile(th_a, (6, 1))
+    theta[[1, 4, 5]] = th_b
+    lml, grad, status = batch.objective(theta, active=[5, 1, 4])
+    assert not status.any()
+    for b in range(6):
+        want = full_b if b in (1, 4, 5) else full_a
+        assert lml[b] == want[0][b]
+        np.testing.assert_array_equal(grad[b], want[1][b])
+    with pytest.raises(IndexError):
+        batch.objective(theta, active=[6])
