@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6
 BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mean/cov written
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
-# Measured HBM bytes per track-step (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.csv).
+# Measured HBM bytes per track-step (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic_v6_quad.csv).
 # Above the algorithmic figure by the rts_work rows the forward pass hands to the smoother.
 TRAFFIC_FWD = 441
 TRAFFIC_BWD = 337 + 560  # urtss_gain_kernel + urtss_combine_l1
