@@ -320,6 +320,278 @@ __global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Column-ordered panel kernels (large batches).  Measured at 1000 x 2000: the row-ordered kernels above re-read both
+// 64 x 64 operands of every tile product from HBM -- 394 GB per gp_potrf launch, 4.2 TB/s, HBM-bound
+// (profiles/r01_gp_pmc_hbm_traffic_1000x2000.csv).  In column order the tiles of one block column are independent and
+// share one operand (row panel j of L), so a workgroup takes four of them at a time, one 64 x 64 tile per wave:
+//   * the shared panel goes through LDS once per workgroup (double-buffered 64 x 64 blocks, one barrier per block),
+//   * each wave streams its own rows from global memory into four rotating fragment sets (refilled right after use:
+//     three sub-blocks = ~6000 MFMA cycles of prefetch distance at one wave per SIMD),
+//   * the product is accumulated TRANSPOSED (shared rows index the accumulator rows), because a 16x16x4 accumulator --
+//     lane l holds rows (l>>4) + 4 reg of column l&15 -- is exactly the B operand of the next MFMA: the multiplication
+//     by the inverted diagonal block, Dinv * S^T, consumes the accumulators in place with no LDS or memory round trip.
+// Bytes per tile product: 32 KB own rows + 32/4 KB shared = 40 KB instead of 64 KB.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LDB = T + 2;  // LDS row stride of a staged 64 x 64 block: 528 B keeps 16-byte alignment and spreads banks
+
+struct RowFrag {
+    v4d v[4];  // rows r + 16 n (n = 0..3) of a 64-row operand, 4 consecutive k per lane
+};
+__device__ __forceinline__ void load_rows(RowFrag& f, const double* const (&pr)[4], int k) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) f.v[n] = *reinterpret_cast<const v4d*>(pr[n] + k);
+}
+__device__ __forceinline__ void stage_load(v4d (&st)[4], const double* src, size_t ld, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        st[q] = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 4);
+    }
+}
+__device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = st[q];
+    }
+}
+// acc[m][n] += shared[16 m + ..][k] * own[16 n + ..][k] for one 16-k sub-block; shared fragments come from LDS
+__device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
+                                        bool live) {
+    v4d a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+    }
+}
+// accT += sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T.  `shared` points at row 0 / column 0
+// of the shared 64-row panel; this wave only accumulates blocks >= wb0 (its operand is structurally zero before that).
+// Every thread of the workgroup must call this with the same kb0, kb1 (it contains barriers).
+__device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
+                                             const double* const (&own)[4], int kb0, int kb1, int wb0, double* stage,
+                                             int tid, int lane) {
+    if (kb0 >= kb1) return;
+    const int r = lane & 15, g = lane >> 4;
+    v4d st[4];
+    stage_load(st, shared + (size_t)kb0 * T, lds_ld, tid);
+    RowFrag f0, f1, f2, f3;
+    load_rows(f0, own, kb0 * T);
+    load_rows(f1, own, kb0 * T + 16);
+    load_rows(f2, own, kb0 * T + 32);
+    load_rows(f3, own, kb0 * T + 48);
+    stage_store(stage, st, tid);
+    __syncthreads();
+    for (int kb = kb0; kb < kb1; ++kb) {
+        double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
+        double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
+        const bool more = kb + 1 < kb1, live = kb >= wb0;
+        const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
+        stage_load(st, shared + (size_t)kn, lds_ld, tid);
+        mma_sub(acc, cur, 0, f0, r, g, live);
+        load_rows(f0, own, kn);
+        mma_sub(acc, cur, 1, f1, r, g, live);
+        load_rows(f1, own, kn + 16);
+        mma_sub(acc, cur, 2, f2, r, g, live);
+        load_rows(f2, own, kn + 32);
+        mma_sub(acc, cur, 3, f3, r, g, live);
+        load_rows(f3, own, kn + 48);
+        stage_store(nxt, st, tid);
+        __syncthreads();
+    }
+}
+// For m2 = 0..3: row[n] = sum_m sum_e Dl[16 m2 + r][16 m + 4 e + g] * in[m][n][e], handed to f(m2, row) one block row at
+// a time so that only four result tiles are live (Dl: 64 x 64 in LDS, leading dimension LD).
+template <typename F>
+__device__ __forceinline__ void left_mul_lds(const double* Dl, const v4d (&in)[4][4], int r, int g, F f) {
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) {
+        v4d row[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) row[n] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double a = Dl[(16 * m2 + r) * LD + 16 * m + 4 * e + g];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    row[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, in[m][n][e], row[n], 0, 0, 0);
+            }
+        f(m2, row);
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky factor and inverse of one 64 x 64 diagonal block by ONE wave, rows in registers: lane r holds row r of the
+// block (64 doubles), a column step broadcasts the scaled column through v_readlane (scalar operands of the FMAs), and
+// there is no barrier and no LDS traffic inside either loop nest -- ~2 x 2016 FMAs + readlanes, a few tens of
+// microseconds, where the 256-thread LDS version (chol64 + trinv64: 192 barriers, a 64-thread substitution) took ~250.
+// In:  S = the symmetric block (row-major, leading dimension LD).  Out: S = L (lower triangle, upper part zeroed),
+// X = L^-1 (lower triangular, zeros above).  *ok is cleared when a pivot is not positive.
+__device__ void chol_trinv_wave(double* S, double* X, int lane, int* ok) {
+    double a[T];
+#pragma unroll
+    for (int c = 0; c < T; ++c) a[c] = S[lane * LD + c];
+    bool good = true;
+#pragma unroll
+    for (int c = 0; c < T; ++c) {
+        const double piv = readlane_f64(a[c], c);
+        good = good && (piv > 0.0);
+        const double rd = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+        const double l = a[c] * rd;  // lane c: sqrt(piv); lanes below: the column of L; lanes above: unused
+        a[c] = l;
+#pragma unroll
+        for (int cc = c + 1; cc < T; ++cc) a[cc] = fma(-l, readlane_f64(l, cc), a[cc]);
+    }
+    if (!good && lane == 0) *ok = 0;
+    // lane c solves L x = e_c by forward substitution; L[r][k] is lane r's a[k]
+    double x[T];
+#pragma unroll
+    for (int r = 0; r < T; ++r) {
+        double acc = (lane == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) acc = fma(-readlane_f64(a[k], r), x[k], acc);
+        x[r] = acc / readlane_f64(a[r], r);
+    }
+#pragma unroll
+    for (int c = 0; c < T; ++c) {
+        S[lane * LD + c] = (c <= lane) ? a[c] : 0.0;
+        X[c * LD + lane] = x[c];  // x[c] of lane `lane` = X[row c][column lane]
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
+    __shared__ double S[T * LD];
+    __shared__ double X[T * LD];
+    __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
+    __shared__ int ok;
+    const int b = matrix_of(p, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = nblocks(p.n[b]);
+    const size_t ld = p.ld;
+    double* K = p.K + (size_t)b * ld * ld;
+    double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int r = lane & 15, g = lane >> 4;
+    for (int j = 0; j < nb; ++j) {
+        // Tiles of block column j, four per pass, one per wave; the first pass starts at the diagonal tile itself:
+        //   T(i) = K[i][j] - sum_{k<j} L[i][k] L[j][k]^T;   L[j][j] = chol(T(j));   L[i][j]^T = Dinv_j * T(i)^T
+        for (int i0 = j; i0 < nb; i0 += 4) {
+            const bool mine = i0 + wave < nb;
+            const int i = mine ? i0 + wave : nb - 1;
+            const double* own[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) own[n] = K + (size_t)(i * T + r + 16 * n) * ld + 4 * g;
+            v4d acc[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, 0, stage, tid, lane);
+            // acc[m][n][e] is element (jj = 16 m + 4 e + g, ii = 16 n + r) of the transposed tile
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[m][n][e] = K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g] - acc[m][n][e];
+            const bool diag_wave = (i0 == j) && wave == 0;
+            if (i0 == j) {
+                if (diag_wave) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) S[(16 * n + r) * LD + 16 * m + 4 * e + g] = acc[m][n][e];
+                    // same wave, and LDS operations of one wave complete in order: no barrier before the re-read
+                    chol_trinv_wave(S, X, lane, &ok);
+                }
+                __syncthreads();
+                for (int e = tid; e < T * T; e += 256) {
+                    const int rr = e / T, cc = e % T;
+                    if (cc <= rr) K[(size_t)(j * T + rr) * ld + j * T + cc] = S[rr * LD + cc];
+                    Dinv[(size_t)j * T * T + e] = X[rr * LD + cc];
+                }
+            }
+            if (!diag_wave) {
+                left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
+                    if (!mine) return;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g] = row[n][e];
+                });
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) p.status[b] = ok ? 0 : 1;
+}
+
+// U = L^-T in column order, one workgroup per matrix:  U[a][c]^T = -Dinv_c * (sum_{k in [a, c)} L[c][k] U[a][k]^T)
+__global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
+    __shared__ double X[T * LD];
+    __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
+    const int b = matrix_of(p, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = nblocks(p.n[b]);
+    const size_t ld = p.ld;
+    const double* L = p.K + (size_t)b * ld * ld;
+    double* U = p.U + (size_t)b * ld * ld;
+    const double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
+    const int r = lane & 15, g = lane >> 4;
+    for (int c = 0; c < nb; ++c) {
+        for (int e = tid; e < T * T; e += 256) {
+            const int rr = e / T, cc = e % T;
+            const double d = Dinv[(size_t)c * T * T + e];
+            X[rr * LD + cc] = d;
+            U[(size_t)(c * T + cc) * ld + c * T + rr] = d;                     // U[c][c] = Dinv_c^T
+            if (c & 1) U[(size_t)(c * T + rr) * ld + (c - 1) * T + cc] = 0.0;  // gp_kinv_trace starts 128-aligned
+        }
+        __syncthreads();
+        for (int a0 = 0; a0 < c; a0 += 4) {
+            const bool mine = a0 + wave < c;
+            const int a = mine ? a0 + wave : c - 1;
+            const double* own[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) own[n] = U + (size_t)(a * T + r + 16 * n) * ld + 4 * g;
+            v4d acc[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+            panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a, stage, tid, lane);
+            left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
+                if (!mine) return;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        U[(size_t)(a * T + 16 * n + r) * ld + c * T + 16 * m + 4 * e + g] = -row[n][e];
+            });
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // K^-1 tile (ta >= tb) = sum_{k >= ta} U[ta][k] U[tb][k]^T, reduced against the kernel derivatives:
 //   tr[0] += sum Kinv * Krbf,  tr[1] += sum Kinv * Krbf * d^2,  tr[2] += trace(Kinv)      (off-diagonal tiles count twice)
 // Optionally stores K^-1 (both triangles) into the lower/upper... into `kinv_out` for the predictive variance.
@@ -749,7 +1021,7 @@ int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream) {
     stegp::GpParams p;
     int rc = gp_params(b, &p);
     if (rc) return rc;
-    hipLaunchKernelGGL(stegp::gp_potrf, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
     return gp_hip(hipGetLastError(), "gp_potrf launch");
 }
 
@@ -767,9 +1039,9 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     hipStream_t s = (hipStream_t)stream;
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
     hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, ns), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_potrf, dim3(ns), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(ns), dim3(256), 0, s, p);
     if (ns >= 128)
-        hipLaunchKernelGGL(stegp::gp_trtri<true>, dim3(ns), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(stegp::gp_trtri_cols, dim3(ns), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) {

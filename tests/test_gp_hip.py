@@ -141,3 +141,35 @@ def test_subset_evaluation_matches_full_batch_and_leaves_others_alone():
         np.testing.assert_array_equal(grad[b], want[1][b])
     with pytest.raises(IndexError):
         batch.objective(theta, active=[6])
+
+
+def test_large_batch_kernels_match_small_batch_kernels_and_oracle():
+    """Batches of >= 128 matrices take the column-ordered inverse kernel (gp_trtri_cols); smaller ones the row-ordered
+    one.  Same objective either way, and both agree with the oracle."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    rng = np.random.default_rng(3)
+    B = 136
+    xs, ys = [], []
+    for b in range(B):
+        n = int(rng.integers(40, 331))
+        x = np.insert(np.cumsum(rng.choice([1.0, 2.0, 6.0], n - 1)), 0, 0)
+        f = np.column_stack([np.sin(x / 40.0) + 0.01 * x, np.cos(x / 55.0)])
+        xs.append(x)
+        ys.append(f + rng.normal(0, 0.05, f.shape))
+    theta = np.tile(np.log([2.0, 30.0, 0.01]), (B, 1)) + rng.normal(0, 0.2, (B, 3))
+    big = GpDeviceBatch(xs, ys)
+    lml, grad, status = big.objective(theta)
+    assert not status.any()
+    for lo in range(0, B, 50):
+        hi = min(B, lo + 50)
+        small = GpDeviceBatch(xs[lo:hi], ys[lo:hi])
+        l2, g2, s2 = small.objective(theta[lo:hi])
+        assert not s2.any()
+        np.testing.assert_allclose(lml[lo:hi], l2, rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(grad[lo:hi], g2, rtol=1e-8, atol=1e-7)
+    for b in (0, 57, 135):
+        l, g, _, _ = gpo.lml_and_grad(theta[b], xs[b], ys[b])
+        assert np.isclose(lml[b], l, rtol=1e-10, atol=1e-8)
+        np.testing.assert_allclose(grad[b], g, rtol=1e-7, atol=1e-6)
