@@ -352,7 +352,7 @@ __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = tid + 256 * q;
-        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = st[q];
+        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -st[q];  // the panel is staged NEGATED
     }
 }
 // acc[m][n] += shared[16 m + ..][k] * own[16 n + ..][k] for one 16-k sub-block; shared fragments come from LDS
@@ -371,7 +371,8 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
     }
 }
-// accT += sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T.  `shared` points at row 0 / column 0
+// accT -= sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T (both callers subtract the product, so
+// the shared panel is negated once on its way into LDS).  `shared` points at row 0 / column 0
 // of the shared 64-row panel; this wave only accumulates blocks >= wb0 (its operand is structurally zero before that).
 // Every thread of the workgroup must call this with the same kb0, kb1 (it contains barriers).
 __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
@@ -435,16 +436,18 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 }
 
 // Cholesky factor and inverse of one 64 x 64 diagonal block by ONE wave, rows in registers: lane r holds row r of the
-// block (64 doubles), a column step broadcasts the scaled column through v_readlane (scalar operands of the FMAs), and
-// there is no barrier and no LDS traffic inside either loop nest -- ~2 x 2016 FMAs + readlanes, a few tens of
-// microseconds, where the 256-thread LDS version (chol64 + trinv64: 192 barriers, a 64-thread substitution) took ~250.
+// block (64 doubles).  A column step parks the scaled column in LDS and every lane reads it back with uniform addresses
+// (a broadcast, two values per ds_read_b128); the substitution reads L the same way.  No barrier inside either loop
+// nest -- LDS operations of one wave complete in order -- and ~2 x 2016 FMAs in all, where the 256-thread LDS version
+// (chol64 + trinv64: 192 barriers, a 64-thread substitution) took ~250 us per block.
 // In:  S = the symmetric block (row-major, leading dimension LD).  Out: S = L (lower triangle, upper part zeroed),
-// X = L^-1 (lower triangular, zeros above).  *ok is cleared when a pivot is not positive.
-__device__ void chol_trinv_wave(double* S, double* X, int lane, int* ok) {
+// X = L^-1 (lower triangular, zeros above).  `work` is a 64 x LDB scratch area.  *ok is cleared on a non-positive pivot.
+__device__ void chol_trinv_wave(double* S, double* X, double* work, int lane, int* ok) {
     double a[T];
 #pragma unroll
     for (int c = 0; c < T; ++c) a[c] = S[lane * LD + c];
     bool good = true;
+    double* col = work + T * LDB - T;  // last 64 doubles of the scratch area, 16-byte aligned
 #pragma unroll
     for (int c = 0; c < T; ++c) {
         const double piv = readlane_f64(a[c], c);
@@ -452,18 +455,32 @@ __device__ void chol_trinv_wave(double* S, double* X, int lane, int* ok) {
         const double rd = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
         const double l = a[c] * rd;  // lane c: sqrt(piv); lanes below: the column of L; lanes above: unused
         a[c] = l;
+        col[lane] = l;
+        if (!(c & 1)) a[c + 1] = fma(-l, col[c + 1], a[c + 1]);  // odd head, then 16-byte aligned pairs
 #pragma unroll
-        for (int cc = c + 1; cc < T; ++cc) a[cc] = fma(-l, readlane_f64(l, cc), a[cc]);
+        for (int cc = (c + 2) & ~1; cc < T; cc += 2) {
+            const v2d s2 = *reinterpret_cast<const v2d*>(col + cc);
+            a[cc] = fma(-l, s2[0], a[cc]);
+            a[cc + 1] = fma(-l, s2[1], a[cc + 1]);
+        }
     }
     if (!good && lane == 0) *ok = 0;
-    // lane c solves L x = e_c by forward substitution; L[r][k] is lane r's a[k]
+    // L row-major with 16-byte aligned rows for the broadcast reads of the substitution
+#pragma unroll
+    for (int c = 0; c < T; c += 2) *reinterpret_cast<v2d*>(work + lane * LDB + c) = v2d{a[c], a[c + 1]};
+    // lane c solves L x = e_c by forward substitution
     double x[T];
 #pragma unroll
     for (int r = 0; r < T; ++r) {
-        double acc = (lane == r) ? 1.0 : 0.0;
+        double acc0 = (lane == r) ? 1.0 : 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) acc = fma(-readlane_f64(a[k], r), x[k], acc);
-        x[r] = acc / readlane_f64(a[r], r);
+        for (int k = 0; k + 1 < r; k += 2) {
+            const v2d l2 = *reinterpret_cast<const v2d*>(work + r * LDB + k);
+            acc0 = fma(-l2[0], x[k], acc0);
+            acc1 = fma(-l2[1], x[k + 1], acc1);
+        }
+        if (r & 1) acc0 = fma(-work[r * LDB + r - 1], x[r - 1], acc0);
+        x[r] = (acc0 + acc1) / work[r * LDB + r];
     }
 #pragma unroll
     for (int c = 0; c < T; ++c) {
@@ -495,20 +512,17 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
             const double* own[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) own[n] = K + (size_t)(i * T + r + 16 * n) * ld + 4 * g;
+            // acc[m][n][e] is element (jj = 16 m + 4 e + g, ii = 16 n + r) of the transposed tile; it starts as K[i][j]^T
+            // (loads in flight behind the first panel blocks) and the negated panel products are accumulated onto it
             v4d acc[4][4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, 0, stage, tid, lane);
-            // acc[m][n][e] is element (jj = 16 m + 4 e + g, ii = 16 n + r) of the transposed tile
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[m][n][e] = K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g] - acc[m][n][e];
+                        acc[m][n][e] = K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g];
+            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, 0, stage, tid, lane);
             const bool diag_wave = (i0 == j) && wave == 0;
             if (i0 == j) {
                 if (diag_wave) {
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) S[(16 * n + r) * LD + 16 * m + 4 * e + g] = acc[m][n][e];
                     // same wave, and LDS operations of one wave complete in order: no barrier before the re-read
-                    chol_trinv_wave(S, X, lane, &ok);
+                    chol_trinv_wave(S, X, stage, lane, &ok);
                 }
                 __syncthreads();
                 for (int e = tid; e < T * T; e += 256) {
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
     if (tid == 0) p.status[b] = ok ? 0 : 1;
 }
 
-// U = L^-T in column order, one workgroup per matrix:  U[a][c]^T = -Dinv_c * (sum_{k in [a, c)} L[c][k] U[a][k]^T)
+// U = L^-T in column order, one workgroup per matrix:  U[a][c]^T = Dinv_c * (-sum_{k in [a, c)} L[c][k] U[a][k]^T)
 __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
     __shared__ double X[T * LD];
     __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        U[(size_t)(a * T + 16 * n + r) * ld + c * T + 16 * m + 4 * e + g] = -row[n][e];
+                        U[(size_t)(a * T + 16 * n + r) * ld + c * T + 16 * m + 4 * e + g] = row[n][e];
             });
         }
         __threadfence_block();
@@ -727,6 +741,8 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
 __device__ __forceinline__ double* gp_wbuf(const GpParams& p, int b) { return p.Dinv + (size_t)b * p.nb_max * T * T; }
 __device__ __forceinline__ double* gp_share(const GpParams& p, int b) { return gp_wbuf(p, b) + (size_t)p.nout * p.ld; }
 
+constexpr int kMaxOut = 4;  // ste_gp_batch_f64.nout <= 4
+
 __global__ __launch_bounds__(64) void gp_w(const GpParams p) {
     const int b = matrix_of(p, blockIdx.y), kb = blockIdx.x, lane = threadIdx.x;
     const int n = p.n[b], nb = nblocks(n);
@@ -735,17 +751,34 @@ __global__ __launch_bounds__(64) void gp_w(const GpParams p) {
     const double* U = p.U + (size_t)b * ld * ld;
     const int k = kb * T + lane;
     const int amax = (k < n ? k : n - 1);
-    for (int o = 0; o < p.nout; ++o) {
-        const double* y = p.y + ((size_t)b * p.nout + o) * p.nmax;
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int a = 0;
-        for (; a + 8 <= amax + 1; a += 8) {
+    const double* y = p.y + (size_t)b * p.nout * p.nmax;
+    // one pass over the column of U for all outputs (U is the 16 MB operand, y a few KB)
+    double acc[kMaxOut][4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = fma(U[(size_t)(a + u) * ld + k], y[a + u], acc[u]);
-        }
-        for (; a <= amax; ++a) acc[0] = fma(U[(size_t)a * ld + k], y[a], acc[0]);
-        gp_wbuf(p, b)[(size_t)o * ld + k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (int o = 0; o < kMaxOut; ++o)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[o][u] = 0.0;
+    int a = 0;
+    for (; a + 4 <= amax + 1; a += 4) {
+        double uv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) uv[u] = U[(size_t)(a + u) * ld + k];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+            if (o < p.nout) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[o][u] = fma(uv[u], y[(size_t)o * p.nmax + a + u], acc[o][u]);
+            }
     }
+    for (; a <= amax; ++a) {
+        const double uv = U[(size_t)a * ld + k];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+            if (o < p.nout) acc[o][0] = fma(uv, y[(size_t)o * p.nmax + a], acc[o][0]);
+    }
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o)
+        if (o < p.nout) gp_wbuf(p, b)[(size_t)o * ld + k] = (acc[o][0] + acc[o][1]) + (acc[o][2] + acc[o][3]);
 }
 
 __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
@@ -759,24 +792,32 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
     const double* x = p.x + (size_t)b * p.nmax;
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     double yta = 0.0, sl = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0;
-    for (int o = 0; o < p.nout; ++o) {
-        const double* y = p.y + ((size_t)b * p.nout + o) * p.nmax;
-        const double* w = gp_wbuf(p, b) + (size_t)o * ld;
-        double* al = p.alpha + ((size_t)b * p.nout + o) * p.nmax;
-        for (int r = wave; r < T; r += 4) {
-            const int a = ab * T + r;
-            if (a >= n) continue;
-            double acc = 0.0;
-            for (int k = a + lane; k < npad; k += 64) acc = fma(U[(size_t)a * ld + k], w[k], acc);
+    const double* yb = p.y + (size_t)b * p.nout * p.nmax;
+    const double* wb = gp_wbuf(p, b);
+    double* alb = p.alpha + (size_t)b * p.nout * p.nmax;
+    for (int r = wave; r < T; r += 4) {
+        const int a = ab * T + r;
+        if (a >= n) continue;
+        double acc[kMaxOut] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = a + lane; k < npad; k += 64) {
+            const double u = U[(size_t)a * ld + k];  // the row of U is read once for all outputs
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            for (int o = 0; o < kMaxOut; ++o)
+                if (o < p.nout) acc[o] = fma(u, wb[(size_t)o * ld + k], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o >= p.nout) continue;
+            double t = acc[o];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
             if (lane == 0) {
-                al[a] = acc;
-                yta += y[a] * acc;
-                q2 += acc * acc;
-                if (o == 0) sl += log(L[(size_t)a * ld + a]);
+                alb[(size_t)o * p.nmax + a] = t;
+                yta += yb[(size_t)o * p.nmax + a] * t;
+                q2 += t * t;
             }
         }
+        if (lane == 0) sl += log(L[(size_t)a * ld + a]);
     }
     if (p.grad) {
         // alpha^T (dK/dtheta) alpha restricted to the rows of this block needs the whole alpha vector, which the other
@@ -795,32 +836,37 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
     (void)x; (void)c; (void)inv_l;
 }
 
-// alpha^T Krbf alpha and alpha^T (Krbf o d^2) alpha, rows of one 64-row block against all columns (n^2 exps per output,
-// spread over nb workgroups per matrix).
+// alpha^T Krbf alpha and alpha^T (Krbf o d^2) alpha summed over the outputs: rows of one 64-row block against the columns
+// j <= i (the form is symmetric: pairs below the diagonal count twice), one exp per pair shared by all outputs.
 __global__ __launch_bounds__(256) void gp_quad(const GpParams p) {
     __shared__ double red[2][4];
     const int b = matrix_of(p, blockIdx.y), ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = p.n[b], nb = nblocks(n);
     if (ab >= nb) return;
     const double* x = p.x + (size_t)b * p.nmax;
+    const double* al = p.alpha + (size_t)b * p.nout * p.nmax;
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     double q0 = 0.0, q1 = 0.0;
-    for (int o = 0; o < p.nout; ++o) {
-        const double* al = p.alpha + ((size_t)b * p.nout + o) * p.nmax;
-        for (int r = wave; r < T; r += 4) {
-            const int i = ab * T + r;
-            if (i >= n) continue;
-            const double ai = al[i], xi = x[i];
-            double r0 = 0.0, r1 = 0.0;
-            for (int j = lane; j < n; j += 64) {
-                const double d = (xi - x[j]) * inv_l, d2 = d * d;
-                const double kr = c * exp(-0.5 * d2) * al[j];
-                r0 += kr;
-                r1 += kr * d2;
-            }
-            q0 += ai * r0;
-            q1 += ai * r1;
+    for (int r = wave; r < T; r += 4) {
+        const int i = ab * T + r;
+        if (i >= n) continue;
+        const double xi = x[i];
+        double ai[kMaxOut];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) ai[o] = o < p.nout ? al[(size_t)o * p.nmax + i] : 0.0;
+        double r0 = 0.0, r1 = 0.0;
+        for (int j = lane; j <= i; j += 64) {
+            const double d = (xi - x[j]) * inv_l, d2 = d * d;
+            double aa = 0.0;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o)
+                if (o < p.nout) aa = fma(ai[o], al[(size_t)o * p.nmax + j], aa);
+            const double kr = (j < i ? 2.0 : 1.0) * c * exp(-0.5 * d2) * aa;
+            r0 += kr;
+            r1 += kr * d2;
         }
+        q0 += r0;
+        q1 += r1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
