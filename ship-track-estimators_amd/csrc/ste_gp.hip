@@ -608,110 +608,82 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // K^-1 tile (ta >= tb) = sum_{k >= ta} U[ta][k] U[tb][k]^T, reduced against the kernel derivatives:
 //   tr[0] += sum Kinv * Krbf,  tr[1] += sum Kinv * Krbf * d^2,  tr[2] += trace(Kinv)      (off-diagonal tiles count twice)
-// Optionally stores K^-1 (both triangles) into the lower/upper... into `kinv_out` for the predictive variance.
+// and optionally stored (both triangles) into `kinv_out` for the predictive variance.
+// One workgroup per strip = block row ta x four block columns tb (one 64 x 64 tile per wave): all four contractions run
+// over the same k-range [ta, nb) and share the rows of U[ta], which is exactly the shape of panel_gemm_t -- shared rows
+// through LDS, own rows through four rotating fragment sets.
 // ---------------------------------------------------------------------------------------------------------------
-// 128 x 128 output tiles (each wave a 64 x 64 block = 4 x 4 MFMA tiles): per unit of matrix work this streams half the
-// bytes of 64 x 64 tiles (16 flop/B instead of 8), and the three n^3/3 phases are HBM-bound at config-5 batch sizes.
-// Row blocks past the end of an odd-sized matrix are redirected to row 0 and their results dropped; the 64 x 64 tile just
-// below the diagonal of every odd block row of U is zero-filled by gp_trtri so that the contraction can start at the
-// 128-aligned column.
-struct Frag64 {
-    v4d a[4], b[4];
-};
-__device__ __forceinline__ void load_frag64(Frag64& f, const double* const (&pa)[4], const double* const (&pb)[4], int k) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f.a[m] = *reinterpret_cast<const v4d*>(pa[m] + k);
-        f.b[m] = *reinterpret_cast<const v4d*>(pb[m] + k);
-    }
-}
-__device__ __forceinline__ void mma_frag64(v4d (&acc)[4][4], const Frag64& f) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[m][e], f.b[n][e], acc[m][n], 0, 0, 0);
-}
-// Two fragment sets ping-pong; every refill is unconditional (the tail re-reads the first chunk and discards it) so
-// that hipcc can count the loads in flight instead of draining the queue where a branch would rejoin.
-__device__ __forceinline__ void wave_gemm_nt64(v4d (&acc)[4][4], const double* const (&pa)[4],
-                                               const double* const (&pb)[4], int k0, int k1) {
-    if (k0 >= k1) return;
-    Frag64 p, q;
-    load_frag64(p, pa, pb, k0);
-    for (int k = k0; k < k1; k += 32) {
-        load_frag64(q, pa, pb, k + 16 < k1 ? k + 16 : k0);
-        mma_frag64(acc, p);
-        load_frag64(p, pa, pb, k + 32 < k1 ? k + 32 : k0);
-        if (k + 16 < k1) mma_frag64(acc, q);
-    }
+__host__ __device__ inline int kinv_strips(int nb) {  // strips of a matrix with nb block rows, in (ta, group) order
+    int s = 0;
+    for (int ta = 0; ta < nb; ++ta) s += (ta + 4) / 4;
+    return s;
 }
 
 __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* kinv_out) {
     __shared__ double red[3][4];
+    __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
     // XCD-aware mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with a
-    // (tile, matrix) grid one matrix's tiles would land on all eight.  Here ids that are congruent mod 8 -- the ones
-    // that share an XCD -- walk the tiles of the SAME matrix in order, so the U rows a tile row re-reads come from that
-    // XCD's L2 instead of HBM.  Placement only affects speed: every tile is still computed exactly once.
-    const int nb2_max = (p.nb_max + 1) / 2;
-    const int ntile_grid = nb2_max * (nb2_max + 1) / 2;
+    // (strip, matrix) grid one matrix's strips would land on all eight.  Here ids that are congruent mod 8 -- the ones
+    // that share an XCD -- walk the strips of the SAME matrix in order, so the U rows a strip re-reads come from that
+    // XCD's L2 instead of HBM (measured: 42 GB per launch at 1000 x 2000 instead of ~400).  Placement only affects
+    // speed: every tile is still computed exactly once.
+    const int nstrip_grid = kinv_strips(p.nb_max);
     const int id = blockIdx.x, slot = id >> 3;
-    const int bslot = (slot / ntile_grid) * 8 + (id & 7);
+    const int bslot = (slot / nstrip_grid) * 8 + (id & 7);
     if (bslot >= p.nslots) return;
     const int b = matrix_of(p, bslot);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = p.n[b], nb = nblocks(n), nb2 = (nb + 1) / 2;
-    int tile = slot % ntile_grid;
-    int ta = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
-    while (ta * (ta + 1) / 2 > tile) --ta;
-    const int tb = tile - ta * (ta + 1) / 2;
-    if (ta >= nb2) return;
+    const int n = p.n[b], nb = nblocks(n);
+    const int strip = slot % nstrip_grid;
+    int ta = 0, first = 0;
+    while (ta < p.nb_max && first + (ta + 4) / 4 <= strip) {
+        first += (ta + 4) / 4;
+        ++ta;
+    }
+    if (ta >= nb) return;
+    const int tb0 = 4 * (strip - first);
+    const bool mine = tb0 + wave <= ta;
+    const int tb = mine ? tb0 + wave : ta;
     const size_t ld = p.ld;
     const double* U = p.U + (size_t)b * ld * ld;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    const int r16 = lane & 15, g = lane >> 4, nrows = nb * T;
-    const double* pa[4];
-    const double* pb[4];
+    const int r = lane & 15, g = lane >> 4, nrows = nb * T;
+    const double* own[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ra = ta * 128 + wr + 16 * m, rb = tb * 128 + wc + 16 * m;
-        pa[m] = U + (size_t)((ra < nrows ? ra : 0) + r16) * ld + 4 * g;
-        pb[m] = U + (size_t)((rb < nrows ? rb : 0) + r16) * ld + 4 * g;
-    }
+    for (int m = 0; m < 4; ++m) own[m] = U + (size_t)(tb * T + r + 16 * m) * ld + 4 * g;
     v4d acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) acc[m][nn] = v4d{0.0, 0.0, 0.0, 0.0};
-    wave_gemm_nt64(acc, pa, pb, ta * 128, nb * T);
+    panel_gemm_t(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, ta, stage, tid, lane);
+    // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = tb*64 + 16 nn + r (own rows)
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     const double* x = p.x + (size_t)b * p.nmax;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     const double wgt = (ta == tb) ? 1.0 : 2.0;
+    if (mine) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
+            for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gr = ta * 128 + wr + 16 * m + (lane >> 4) + 4 * e, gc = tb * 128 + wc + 16 * nn + (lane & 15);
-                const double v = acc[m][nn][e];
-                if (gr < n && gc < n) {
-                    const double d = (x[gr] - x[gc]) * inv_l;
-                    const double d2 = d * d;
-                    const double kr = c * exp(-0.5 * d2);
-                    t0 += wgt * v * kr;
-                    t1 += wgt * v * kr * d2;
-                    if (gr == gc) t2 += v;
+                for (int e = 0; e < 4; ++e) {
+                    const int gr = ta * T + 16 * m + 4 * e + g, gc = tb * T + 16 * nn + r;
+                    const double v = -acc[m][nn][e];
+                    if (gr < n && gc < n) {
+                        const double d = (x[gr] - x[gc]) * inv_l;
+                        const double d2 = d * d;
+                        const double kr = c * exp(-0.5 * d2);
+                        t0 += wgt * v * kr;
+                        t1 += wgt * v * kr * d2;
+                        if (gr == gc) t2 += v;
+                    }
+                    if (kinv_out && gr < nrows && gc < nrows) {
+                        kinv_out[(size_t)b * ld * ld + (size_t)gr * ld + gc] = v;
+                        kinv_out[(size_t)b * ld * ld + (size_t)gc * ld + gr] = v;
+                    }
                 }
-                if (kinv_out && gr < nrows && gc < nrows) {
-                    kinv_out[(size_t)b * ld * ld + (size_t)gr * ld + gc] = v;
-                    kinv_out[(size_t)b * ld * ld + (size_t)gc * ld + gr] = v;
-                }
-            }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         t0 += __shfl_xor(t0, off);
@@ -725,9 +697,9 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
     }
     __syncthreads();
     if (tid < 3) {
-        // one slot per tile, summed in tile order by gp_finish: bitwise reproducible, unlike an atomic accumulation
+        // one slot per strip, summed in strip order by gp_finish: bitwise reproducible, unlike an atomic accumulation
         const int ntiles = p.nb_max * (p.nb_max + 1) / 2;
-        p.tr[((size_t)b * 3 + tid) * ntiles + tile] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        p.tr[((size_t)b * 3 + tid) * ntiles + strip] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
 }
 
@@ -892,7 +864,7 @@ __global__ __launch_bounds__(64) void gp_finish(const GpParams p) {
         for (int i = 0; i < nb; ++i) r[v] += sh[(size_t)v * p.nb_max + i];
     p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
     if (p.grad) {
-        const int ntiles = p.nb_max * (p.nb_max + 1) / 2, nb2 = (nb + 1) / 2, mine = nb2 * (nb2 + 1) / 2;
+        const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = kinv_strips(nb);
         double tr[3];
         for (int v = 0; v < 3; ++v) {
             double acc = 0.0;
@@ -1091,9 +1063,8 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     else
         hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) {
-        const unsigned groups = (ns + 7) / 8;
-        const unsigned nb2 = (unsigned)((p.nb_max + 1) / 2), tiles128 = nb2 * (nb2 + 1) / 2;
-        hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * tiles128), dim3(256), 0, s, p, b->Kinv);
+        const unsigned groups = (ns + 7) / 8, strips = (unsigned)stegp::kinv_strips(p.nb_max);
+        hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * strips), dim3(256), 0, s, p, b->Kinv);
     }
     hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, ns), dim3(64), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, ns), dim3(256), 0, s, p);
