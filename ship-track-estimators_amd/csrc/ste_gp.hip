@@ -7,8 +7,9 @@
 // eq. 5.9).  This file evaluates that objective for a batch of tracks with hand-written kernels:
 //
 //   gp_kbuild      K = c exp(-(xi-xj)^2 / 2 l^2) + (s + jitter) I, lower 64x64 tiles, identity padding
-//   gp_potrf       blocked left-looking Cholesky, one workgroup per matrix, tile products on fp64 MFMA
-//   gp_trtri       U = L^-T (upper, row-major), one workgroup per (matrix, block row)
+//   gp_potrf_cols  blocked left-looking Cholesky in column order, one workgroup per matrix, four tiles per pass
+//   gp_trtri_cols  U = L^-T (upper, row-major) in column order (large batches); gp_trtri<false>: one workgroup per
+//                  (matrix, block row) for small batches
 //   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised) -> gradient
 //   gp_w / gp_alpha / gp_quad / gp_finish   alpha = U (U^T y), log-marginal likelihood, gradient assembly
 //   gp_kstar / gp_predict   posterior mean and variance at new times (variance as a tile GEMM against K^-1)
@@ -771,8 +772,21 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
         const int a = ab * T + r;
         if (a >= n) continue;
         double acc[kMaxOut] = {0.0, 0.0, 0.0, 0.0};
-        for (int k = a + lane; k < npad; k += 64) {
-            const double u = U[(size_t)a * ld + k];  // the row of U is read once for all outputs
+        const double* urow = U + (size_t)a * ld;  // the row of U is read once for all outputs, four loads in flight
+        int k = a + lane;
+        for (; k + 192 < npad; k += 256) {
+            double u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = urow[k + 64 * q];
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o)
+                if (o < p.nout) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[o] = fma(u[q], wb[(size_t)o * ld + k + 64 * q], acc[o]);
+                }
+        }
+        for (; k < npad; k += 64) {
+            const double u = urow[k];
 #pragma unroll
             for (int o = 0; o < kMaxOut; ++o)
                 if (o < p.nout) acc[o] = fma(u, wb[(size_t)o * ld + k], acc[o]);
