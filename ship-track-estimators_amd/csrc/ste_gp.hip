@@ -8,7 +8,7 @@
 //
 //   gp_kbuild      K = c exp(-(xi-xj)^2 / 2 l^2) + (s + jitter) I, lower 64x64 tiles, identity padding
 //   gp_potrf_cols  blocked left-looking Cholesky in column order, one workgroup per matrix, four tiles per pass
-//   gp_trtri_cols  U = L^-T (upper, row-major) in column order (large batches); gp_trtri<false>: one workgroup per
+//   gp_trtri_cols  U = L^-T (upper, row-major) in column order (large batches); gp_trtri_rows: one workgroup per
 //                  (matrix, block row) for small batches
 //   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised) -> gradient
 //   gp_w / gp_alpha / gp_quad / gp_finish   alpha = U (U^T y), log-marginal likelihood, gradient assembly
@@ -149,127 +149,20 @@ __global__ __launch_bounds__(256) void gp_kbuild(const GpParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 64x64 diagonal-block kernels in LDS (row-major, leading dimension 65 to spread banks)
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int LD = T + 1;
-
-// In-place Cholesky of the lower triangle of S (64x64); returns false through *ok if a pivot is not positive.
-__device__ void chol64(double* S, int tid, int* ok) {
-    for (int c = 0; c < T; ++c) {
-        __syncthreads();
-        const double d = S[c * LD + c];
-        if (!(d > 0.0)) {
-            if (tid == 0) *ok = 0;
-        }
-        const double rd = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-        __syncthreads();
-        for (int r = c + tid; r < T; r += 256) S[r * LD + c] = (r == c) ? d * rd : S[r * LD + c] * rd;
-        __syncthreads();
-        // trailing update of the lower triangle: S[r][cc] -= S[r][c] * S[cc][c], r >= cc > c
-        const int m = T - 1 - c;
-        for (int e = tid; e < m * m; e += 256) {
-            const int r = c + 1 + e / m, cc = c + 1 + e % m;
-            if (cc <= r) S[r * LD + cc] -= S[r * LD + c] * S[cc * LD + c];
-        }
-    }
-    __syncthreads();
-}
-
-// X = L^-1 for the lower-triangular L in S (64x64), written to X (LDS, same layout); 64 threads, one column each.
-__device__ void trinv64(const double* S, double* X, int tid) {
-    if (tid < T) {
-        const int c = tid;
-        for (int r = 0; r < T; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
-            for (int k = c; k < r; ++k) acc -= S[r * LD + k] * X[k * LD + c];
-            X[r * LD + c] = (r < c) ? 0.0 : acc / S[r * LD + r];
-        }
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Blocked left-looking Cholesky, one workgroup (4 waves) per matrix.  L overwrites the lower triangle of K.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_potrf(const GpParams p) {
-    __shared__ double S[T * LD];
-    __shared__ double X[T * LD];
-    __shared__ int ok;
-    const int b = matrix_of(p, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nb = nblocks(p.n[b]);
-    const size_t ld = p.ld;
-    double* K = p.K + (size_t)b * ld * ld;
-    double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
-    if (tid == 0) ok = 1;
-    __syncthreads();
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-    for (int i = 0; i < nb; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            v4d acc[2][2];
-            zero_acc(acc);
-            wave_gemm_nt(acc, K + (size_t)(i * T + wr) * ld, ld, K + (size_t)(j * T + wc) * ld, ld, 0, j * T, lane);
-            // C = A[i][j] - acc  -> LDS
-            for_each_acc(acc, wave, lane, [&](int r, int c, double v) {
-                S[r * LD + c] = K[(size_t)(i * T + r) * ld + j * T + c] - v;
-            });
-            __syncthreads();
-            if (j < i) {
-                // L[i][j] = C * Dinv_j^T   (NT product with A = C in LDS, B = Dinv_j in global)
-                v4d a2[2][2];
-                zero_acc(a2);
-                const int r = lane & 15, g = lane >> 4;
-                const double* Dj = Dinv + (size_t)j * T * T;
-                for (int k = 0; k < T; k += 16) {
-                    double a0[4], a1[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a0[e] = S[(wr + r) * LD + k + 4 * g + e];
-                        a1[e] = S[(wr + 16 + r) * LD + k + 4 * g + e];
-                    }
-                    const v4d b0 = *reinterpret_cast<const v4d*>(Dj + (size_t)(wc + r) * T + k + 4 * g);
-                    const v4d b1 = *reinterpret_cast<const v4d*>(Dj + (size_t)(wc + 16 + r) * T + k + 4 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b0[e], a2[0][0], 0, 0, 0);
-                        a2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], b1[e], a2[0][1], 0, 0, 0);
-                        a2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b0[e], a2[1][0], 0, 0, 0);
-                        a2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], b1[e], a2[1][1], 0, 0, 0);
-                    }
-                }
-                for_each_acc(a2, wave, lane, [&](int rr, int cc, double v) {
-                    K[(size_t)(i * T + rr) * ld + j * T + cc] = v;
-                });
-            } else {
-                chol64(S, tid, &ok);
-                trinv64(S, X, tid);
-                for (int e = tid; e < T * T; e += 256) {
-                    const int r = e / T, c = e % T;
-                    if (c <= r) K[(size_t)(i * T + r) * ld + i * T + c] = S[r * LD + c];
-                    Dinv[(size_t)i * T * T + e] = X[r * LD + c];
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-    }
-    if (tid == 0) p.status[b] = ok ? 0 : 1;
-}
+constexpr int LD = T + 1;  // leading dimension of the 64 x 64 diagonal-block buffers in LDS (spreads banks)
 
 // ---------------------------------------------------------------------------------------------------------------
 // U = L^-T (upper triangular, row-major).  Row block a of U depends only on L and Dinv: one workgroup per (a, matrix).
 //   U[a][a] = Dinv_a^T ;  U[a][b] = -( sum_{k in [a, b)} U[a][k] L[b][k]^T ) Dinv_b^T   for b > a
 // ---------------------------------------------------------------------------------------------------------------
-// kPerMatrix: one workgroup walks all block rows of its matrix (grid = B).  With hundreds of matrices in flight that
-// keeps one row stream per CU instead of thousands chip-wide and measured 2x faster; small batches use one workgroup
-// per block row (grid = nb x B) for parallelism.
-template <bool kPerMatrix>
-__global__ __launch_bounds__(256) void gp_trtri(const GpParams p) {
+// Row-ordered variant for small batches: one workgroup per (block row, matrix), grid = nb x B, so that a handful of
+// matrices still fills the chip; large batches use gp_trtri_cols below.
+__global__ __launch_bounds__(256) void gp_trtri_rows(const GpParams p) {
     __shared__ double S[T * LD];
-    const int b = matrix_of(p, kPerMatrix ? blockIdx.x : blockIdx.y);
+    const int b = matrix_of(p, blockIdx.y);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = nblocks(p.n[b]);
-    const int a_begin = kPerMatrix ? 0 : blockIdx.x, a_end = kPerMatrix ? nb : blockIdx.x + 1;
+    const int a_begin = blockIdx.x, a_end = blockIdx.x + 1;
     if (a_begin >= nb) return;
     const size_t ld = p.ld;
     for (int a = a_begin; a < a_end; ++a) {
@@ -440,7 +333,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 // block (64 doubles).  A column step parks the scaled column in LDS and every lane reads it back with uniform addresses
 // (a broadcast, two values per ds_read_b128); the substitution reads L the same way.  No barrier inside either loop
 // nest -- LDS operations of one wave complete in order -- and ~2 x 2016 FMAs in all, where the 256-thread LDS version
-// (chol64 + trinv64: 192 barriers, a 64-thread substitution) took ~250 us per block.
+// (column-by-column with three barriers per column, then a 64-thread substitution) took ~250 us per block.
 // In:  S = the symmetric block (row-major, leading dimension LD).  Out: S = L (lower triangle, upper part zeroed),
 // X = L^-1 (lower triangular, zeros above).  `work` is a 64 x LDB scratch area.  *ok is cleared on a non-positive pivot.
 __device__ void chol_trinv_wave(double* S, double* X, double* work, int lane, int* ok) {
@@ -1075,7 +968,7 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     if (ns >= 128)
         hipLaunchKernelGGL(stegp::gp_trtri_cols, dim3(ns), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(stegp::gp_trtri<false>, dim3(p.nb_max, ns), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(stegp::gp_trtri_rows, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) {
         const unsigned groups = (ns + 7) / 8, strips = (unsigned)stegp::kinv_strips(p.nb_max);
         hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * strips), dim3(256), 0, s, p, b->Kinv);
