@@ -336,7 +336,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 // (column-by-column with three barriers per column, then a 64-thread substitution) took ~250 us per block.
 // In:  S = the symmetric block (row-major, leading dimension LD).  Out: S = L (lower triangle, upper part zeroed),
 // X = L^-1 (lower triangular, zeros above).  `work` is a 64 x LDB scratch area.  *ok is cleared on a non-positive pivot.
-__device__ void chol_trinv_wave(double* S, double* X, double* work, int lane, int* ok) {
+__device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work, int lane, int* ok) {
     double a[T];
 #pragma unroll
     for (int c = 0; c < T; ++c) a[c] = S[lane * LD + c];
@@ -416,7 +416,9 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc[m][n][e] = K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g];
-            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, 0, stage, tid, lane);
+            // (first live block passed as a run-time value: with a literal 0 hipcc merges the four sub-blocks of the panel loop
+            //  into one basic block and then shuffles 160 accumulator registers between AGPRs and VGPRs per iteration)
+            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, p.nb_max < 0, stage, tid, lane);
             const bool diag_wave = (i0 == j) && wave == 0;
             if (i0 == j) {
                 if (diag_wave) {
