@@ -2,6 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double v4d __attribute__((ext_vector_type(4)));
+#ifndef SHAREMASK
+#define SHAREMASK 255  // 255: every workgroup streams its own rows; 0: all workgroups read the same, cache-resident rows
+#endif
 constexpr int T = 64, LDB = 66;
 struct RowFrag { v4d v[4]; };
 __device__ __forceinline__ void load_rows(RowFrag& f, const double* const (&pr)[4], int k) {
