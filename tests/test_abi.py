@@ -26,7 +26,8 @@ def test_struct_layout_matches_header():
     from track_estimators._hip import binding
 
     hdr = open(os.path.join(ROOT, "include", "ste.h")).read()
-    for cname, mirror in (("ste_ukf_batch_f64", binding.SteUkfBatchF64), ("ste_gp_batch_f64", binding.SteGpBatchF64)):
+    for cname, mirror in (("ste_ukf_batch_f64", binding.SteUkfBatchF64), ("ste_gp_batch_f64", binding.SteGpBatchF64),
+                          ("ste_prep_batch_f64", binding.StePrepBatchF64)):
         body = hdr[hdr.index("typedef struct %s {" % cname): hdr.index("} %s;" % cname)]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|double)\s*\*?\s*(\w+)\s*;", body)
@@ -47,6 +48,17 @@ def test_argument_validation_without_gpu():
     assert lib.ste_ukf_forward_f64(None, None) == -1
     assert lib.ste_geodetic_dynamics_f64(-1, None, None, None, None, None, None) == -1
     assert lib.ste_geodetic_dynamics_f64(0, None, None, None, None, None, None) == 0
+    # observation preparation: NULL batch, empty batch, unknown model, missing arrays
+    assert lib.ste_track_prep_f64(None, None) == -1
+    pb = binding.StePrepBatchF64()
+    assert lib.ste_track_prep_f64(C.byref(pb), None) == -1
+    pb.B, pb.Tmax, pb.model = 4, 8, 7
+    assert lib.ste_track_prep_f64(C.byref(pb), None) == -1 and b"model" in lib.ste_last_error()
+    pb.model = binding.STE_PREP_WGS84
+    assert lib.ste_track_prep_f64(C.byref(pb), None) == -1 and b"required" in lib.ste_last_error()
+    # GP: NULL batch, subset launch without an index list
+    assert lib.ste_gp_lml_f64(None, None) == -1
+    assert lib.ste_gp_lml_subset_f64(None, 1, None, None) == -1 and b"active" in lib.ste_gp_last_error()
 
 
 def test_no_gpu_fails_loudly():
