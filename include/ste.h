@@ -282,7 +282,7 @@ int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream);
 
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
- *   0 = automatic (a quad per track up to 20 480 tracks per launch, a lane per track above),
+ *   0 = automatic (a quad per track up to 32 768 tracks per launch, a lane per track above),
  *   1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
  * Returns the previous value.  Process-global; not part of the reference-facing surface.
  */

@@ -1215,10 +1215,12 @@ namespace {
 thread_local char g_err[512] = "";
 int g_lanes_per_track = 0;  // 0 = automatic
 // Lane mapping of the sequential kernels.  A quad per track shortens the per-wave instruction stream ~1.7x and puts 4x
-// as many waves on the chip; once a batch fills the SIMDs at one lane per track (measured crossover on MI355X between
-// 10 000 and 40 000 tracks: 5.3 vs 3.1 ms at 10 000, 5.8 vs 9.5 ms at 40 000) the lane-per-track kernels win because
-// they waste no lanes on replicated work.
-constexpr int kQuadMaxTracks = 20480;
+// as many waves on the chip, but replicates work across its lanes and -- at 362 VGPRs -- runs one wave per SIMD, so
+// beyond 16 384 tracks (1 024 waves) the launch takes a second round.  Measured on MI355X, forward + smoother:
+//   tracks      12 288   16 384   20 480   32 768   40 960
+//   quad  ms      4.11     4.65     8.16     9.01    12.85
+//   lane  ms      7.51     7.71     8.47     9.29    10.09
+constexpr int kQuadMaxTracks = 32768;
 int choose_lanes(int B, bool robust) {
     if (robust) return 1;  // the robust update exists in the lane-per-track kernels only
     if (g_lanes_per_track == 1 || g_lanes_per_track == 4) return g_lanes_per_track;
