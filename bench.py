@@ -12,6 +12,12 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline      dominant kernel, algorithmic HBM bytes / HIP-event duration vs 8 TB/s (512 B per
                 track-step for the pair of kernels = 192 B forward + 320 B backward)
   cpu_baseline  the NumPy oracle ("port" of the reference arithmetic) timed on this box's host cores on a bounded sample
+                (one process, and one forked worker per core of the box's CPU share)
+  serial        the same work without overlapping consecutive steps (see --no-pipeline), for the record
+
+Steps are pipelined by default: every step runs the complete forward pass and smoother of one 10 000-track batch, but the
+smoother of step i (latency-bound, 96 CUs) runs beside the forward pass of step i+1 (625 long-running waves, 160 CUs) on
+CU-masked streams, with two sets of history buffers used alternately (track_estimators.batch.SmootherPipeline).
 """
 import argparse
 import json
@@ -103,6 +109,9 @@ def main():
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run forward and smoother of every step back to back on one stream instead of overlapping the "
+                         "smoother of step i with the forward pass of step i+1 on disjoint CU partitions")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--cpu-pool-tracks", type=int, default=768,
@@ -153,6 +162,11 @@ def main():
     sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=rank * B)
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     db = batch.DeviceBatch(hb, device=dev)
+    # Pipelined mode (default): two sets of histories used alternately; the forward pass of step i+1 runs on the first
+    # 160 CUs while the smoother of step i runs on the other 96 (batch.SmootherPipeline).  Every step still does the
+    # whole forward + smoother of one batch; nothing is skipped, the steps overlap.
+    pipe = None if args.no_pipeline else batch.SmootherPipeline(dev, ntracks=B)
+    dbs = [db] if pipe is None else [db, batch.DeviceBatch(hb, device=dev)]
     gathered = None
     if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
@@ -161,33 +175,58 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
-    def one_step(events=None):
+    def serial_step(d, events=None):
         if events is not None:
             events[0].record(stream)
-        db.forward(stream)
+        d.forward(stream)
         if events is not None:
             events[1].record(stream)
-        db.backward(stream)
-        if events is not None:
             events[2].record(stream)
+        d.backward(stream)
+        if events is not None:
+            events[3].record(stream)
         if gathered is not None:
-            gathered.launch(db.sm_mean)
+            gathered.launch(d.sm_mean)
 
-    for _ in range(args.warmup):
-        one_step()
-    if gathered is not None:
-        gathered.finish()
-    torch.cuda.synchronize(dev)
+    def one_step(k, events=None, final=False):
+        d = dbs[k % len(dbs)]
+        if pipe is None:
+            serial_step(d, events)
+        else:
+            pipe.submit(d, after_smoother=(lambda _s: gathered.launch(d.sm_mean)) if gathered is not None else None,
+                        timing=events, final=final)
+
+    def drain():
+        if pipe is not None:
+            pipe.synchronize()
+        if gathered is not None:
+            gathered.finish()
+        torch.cuda.synchronize(dev)
+
+    # back-to-back figure for the record (not the timed region): forward + smoother of one batch on one stream
+    serial_ms = None
+    if pipe is not None and rank == 0:
+        saved, gathered = gathered, None
+        serial_step(db)
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for _ in range(3):
+            serial_step(db)
+        torch.cuda.synchronize(dev)
+        serial_ms = (time.perf_counter() - ts) / 3 * 1e3
+        gathered = saved
+
+    for k in range(args.warmup):
+        one_step(k, final=(k == args.warmup - 1))
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    evs = [[ev(), ev(), ev()] for _ in range(args.steps)]
+    evs = [[ev(), ev(), ev(), ev()] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(evs[k])
-    if gathered is not None:
-        gathered.finish()  # every step's gathered result has landed before the clock stops
-    torch.cuda.synchronize(dev)
+        one_step(k, evs[k], final=(k == args.steps - 1))  # the last smoother has nothing to hide behind: whole chip
+    drain()  # every step's smoother (and gathered result) has landed before the clock stops
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -198,8 +237,10 @@ def main():
         elapsed = float(tt.item())
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     status = db.status_host()
+    for d in dbs[1:]:
+        status = status | d.status_host()
     track_steps_rank = hb.track_steps
     total_units = track_steps_rank * world * args.steps
     value = total_units / elapsed
@@ -208,8 +249,11 @@ def main():
         dom, dom_ms, dom_bytes, dom_traffic = ("urtss_backward", bwd_ms, BYTES_BWD, TRAFFIC_BWD) if bwd_ms >= fwd_ms else (
             "ukf_forward", fwd_ms, BYTES_FWD, TRAFFIC_FWD)
         achieved = dom_bytes * track_steps_rank / (dom_ms * 1e-3) / 1e9
-        pair_gbs = (BYTES_FWD + BYTES_BWD) * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
-        valu_tf = FLOPS_PER_TRACK_STEP * track_steps_rank / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+        # whole-job rates of this rank over the timed region (the two kernels overlap in pipelined mode, so their event
+        # durations no longer add up to the step)
+        per_s = track_steps_rank * args.steps / elapsed
+        pair_gbs = (BYTES_FWD + BYTES_BWD) * per_s / 1e9
+        valu_tf = FLOPS_PER_TRACK_STEP * per_s / 1e12
         out = {
             "metric": "UKF+URTSS track-steps/sec (dim=4, 500-step tracks)",
             "value": value,
@@ -228,9 +272,15 @@ def main():
                             "(BASELINE.json configs[1]); zero injected noise; inputs resident in HBM",
                 "tracks_per_gpu": B, "steps_per_track": int(hb.Nmax), "observations": NOBS, "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (", RCCL all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
+                "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
+                             f"smoother of step i on {pipe.smoother_cus} CUs beside the forward pass of step i+1 on "
+                             f"{pipe.forward_cus} CUs (CU-masked streams, two sets of histories used alternately)"),
                 "lanes_per_track": int(lib.ste_set_lanes_per_track(args.lanes)),
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},
+            "serial": None if serial_ms is None else {
+                "ms_per_step": serial_ms, "value": track_steps_rank / (serial_ms * 1e-3), "unit": "track-steps/s",
+                "note": "one batch, forward then smoother on one unrestricted stream (per GPU, no overlap between steps)"},
             "status_flagged_tracks": int((status != 0).sum()),
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -280,6 +280,19 @@ typedef struct ste_prep_batch_f64 {
 
 int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Stream partitioning for pipelined batches.  At the batch sizes of BASELINE configs[1..2] the forward kernel is a few
+ * hundred long-running waves (10 000 tracks = 625 waves on 1 024 SIMDs) and the smoother is latency-bound, so the
+ * smoother of batch i can run beside the forward pass of batch i+1 -- provided they do not share SIMDs, where each
+ * would take the other's issue slots.  These two calls create / destroy a HIP stream restricted to the compute units
+ * [first_cu, first_cu + num_cus) of the current device (hipExtStreamCreateWithCUMask; on MI355X mask bit n is CU n/8
+ * of XCD n%8, so a contiguous range is spread evenly over the eight XCDs).  Every entry point above accepts such a
+ * stream.  Host plumbing only: nothing of the reference corresponds to it (the reference runs ships one at a time,
+ * examples/example_ukf_rts_smoother_batch.py:19-90).
+ * ------------------------------------------------------------------------------------------------------------- */
+int ste_stream_create_cu_range(int32_t first_cu, int32_t num_cus, void** stream);
+int ste_stream_destroy(void* stream);
+
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
  *   0 = automatic (a quad per track up to 32 768 tracks per launch, a lane per track above),

@@ -1351,6 +1351,32 @@ int ste_set_lanes_per_track(int lanes) {
     return prev;
 }
 
+int ste_stream_create_cu_range(int32_t first_cu, int32_t num_cus, void** stream) {
+    if (!stream) return fail(STE_EINVAL, "stream out-pointer is NULL");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(STE_ENOGPU, "no HIP device");
+    const int ncu = prop.multiProcessorCount;
+    if (first_cu < 0 || num_cus < 1 || first_cu + num_cus > ncu)
+        return fail(STE_EINVAL, "CU range must lie inside [0, multiProcessorCount)");
+    uint32_t mask[32];
+    memset(mask, 0, sizeof(mask));
+    const int words = (ncu + 31) / 32;
+    if (words > 32) return fail(STE_EINVAL, "device has more than 1024 CUs");
+    for (int i = first_cu; i < first_cu + num_cus; ++i) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    int rc = check_hip(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask), "hipExtStreamCreateWithCUMask");
+    if (rc) return rc;
+    *stream = (void*)s;
+    return STE_OK;
+}
+
+int ste_stream_destroy(void* stream) {
+    if (!stream) return STE_OK;
+    return check_hip(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy");
+}
+
 int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream) {
     ste::KParams kp;
     int rc = make_params(b, false, false, &kp);

@@ -138,6 +138,8 @@ SYMBOLS = {
     "ste_gp_lml_subset_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, C.c_void_p]),
     "ste_gp_predict_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
+    "ste_stream_create_cu_range": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "ste_stream_destroy": (C.c_int, [C.c_void_p]),
 }
 
 
