@@ -165,7 +165,12 @@ def main():
     # Pipelined mode (default): two sets of histories used alternately; the forward pass of step i+1 runs on the first
     # 160 CUs while the smoother of step i runs on the other 96 (batch.SmootherPipeline).  Every step still does the
     # whole forward + smoother of one batch; nothing is skipped, the steps overlap.
-    pipe = None if args.no_pipeline else batch.SmootherPipeline(dev, ntracks=B)
+    pipe = None
+    if not args.no_pipeline:
+        try:
+            pipe = batch.SmootherPipeline(dev, ntracks=B)
+        except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
+            print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
     dbs = [db] if pipe is None else [db, batch.DeviceBatch(hb, device=dev)]
     gathered = None
     if dist is not None and not args.no_gather:
