@@ -135,6 +135,14 @@ __device__ __forceinline__ double div_pos(double a, double b) {
     return fma(fma(-b, q, a), r, q);
 }
 
+// dt / kEarthRadius without the division sequence: product with the rounded reciprocal plus one residual correction
+// (the residual is exact in FMA arithmetic, so the result is the correctly rounded quotient except in rare ties).
+__device__ __forceinline__ double div_earth_radius(double a) {
+    constexpr double kInvR = 1.0 / kEarthRadius;
+    const double q = a * kInvR;
+    return fma(fma(-q, kEarthRadius, a), kInvR, q);
+}
+
 // atan2(a, b): a ship moves a small angle per step, so b (= cos(lat') cos(dlon)) is positive and |a| << b almost always.
 __device__ __forceinline__ double atan2_fast(double a, double b) {
     if (__builtin_expect(b > 1e-300 && fabs(a) <= 0.4375 * b, 1)) return atan_small(div_pos(a, b));

@@ -248,7 +248,8 @@ __device__ __forceinline__ int quad_sym_sqrt(const double (&Px)[4], double scale
     const double w = A[0];
     if (w < -1e-12 * wmax) st |= 0x2;
     double Tx[4];
-    quad_recompose(basis.V, sqrt(fmax(w, 0.0)), Tx);
+    // sqrt(max(w, 0)) as w * rsqrt(w): a third of the instructions of the correctly rounded sqrt sequence
+    quad_recompose(basis.V, w > 0.0 ? w * rsqrt_fast(w) : 0.0, Tx);
     xorperm(Tx, cx.q, Tn);
     return st;
 }
@@ -383,7 +384,7 @@ __device__ __forceinline__ void quad_propagate_branching(const double (&x)[4], c
 // leaves their validity range (a pole, a giant step, non-finite data) redoes the step with the branching version.
 __device__ __forceinline__ void quad_propagate(const double (&x)[4], const double (&Tn)[4], double dt, double sr,
                                                double cr, double (&s0)[4], double (&sp)[4], double (&sm)[4]) {
-    const double dt_r = dt / kEarthRadius;
+    const double dt_r = div_earth_radius(dt);
     const double du = sr * dt, da = cr * dt;
     const double lat0 = x[1] * kDeg2Rad, alpha0 = x[3] * kDeg2Rad, delta0 = x[2] * dt_r;
     bool ok = true;
