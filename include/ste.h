@@ -53,6 +53,9 @@ extern "C" {
 /* ste_ukf_batch_f64.flags */
 #define STE_FLAG_SHARED_P0 0x1u        /* P0 is one 4x4 matrix [16] shared by all tracks (else [16][B]) */
 #define STE_FLAG_NO_INITIAL_UPDATE 0x2u /* skip the update with z[:,0] that run() performs before the first predict */
+#define STE_FLAG_SMOOTHER_LANE_PER_TRACK 0x8u /* run the smoother's recurrence with one lane per track whatever the batch
+                                                  size: a quarter of the waves, each longer -- the right shape when the
+                                                  smoother shares the GPU with another kernel (batch.SmootherPipeline) */
 #define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
                                 the reference ships with its call site commented out, :228) */
 

@@ -1320,7 +1320,7 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
             int rc = check_hip(hipGetLastError(), "urtss_gain launch");
             if (rc) return rc;
         }
-        if (choose_lanes(kp.B, false) == 4) {
+        if (!(kp.flags & STE_FLAG_SMOOTHER_LANE_PER_TRACK) && choose_lanes(kp.B, false) == 4) {
             const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
             hipLaunchKernelGGL(ste::urtss_combine_q4, dim3(gridq), dim3(64), 0, s, kp);
         } else {

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("STE_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libs
 STE_FLAG_SHARED_P0 = 0x1
 STE_FLAG_NO_INITIAL_UPDATE = 0x2
 STE_FLAG_ROBUST = 0x4
+STE_FLAG_SMOOTHER_LANE_PER_TRACK = 0x8
 
 STE_STATUS_NAN = 0x1
 STE_STATUS_CLAMPED = 0x2

@@ -54,3 +54,12 @@ def test_pipeline_hooks_and_timing_events():
     with pytest.raises(ValueError):
         batch.SmootherPipeline("cuda:0", forward_cus=10_000)
     pipe.close()
+    # opt-in: lane-per-track recurrence on the smoother partition (different rounding, same answer)
+    ref = dbs[0].sm_mean.clone()
+    pipe = batch.SmootherPipeline("cuda:0", forward_cus=160, smoother_lane_per_track=True)
+    pipe.submit(dbs[0])
+    pipe.submit(dbs[1], final=True)
+    pipe.synchronize()
+    assert float((dbs[0].sm_mean - ref).abs().max() / ref.abs().max()) < 1e-10
+    assert dbs[0].struct.flags & 0x8 == 0  # the flag is not left behind on the batch
+    pipe.close()
