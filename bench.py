@@ -103,8 +103,8 @@ def cpu_baseline_pool(procs: int, tracks_per_proc: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="tracks per GPU")
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
