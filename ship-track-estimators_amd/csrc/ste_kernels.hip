@@ -127,13 +127,8 @@ __device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)
 // The 2n points come in +- pairs around the centre, so their angles are (centre angle) +- (small increment) and
 // sin/cos of all of them follow from the centre's three sincos and one sincos per increment by the angle-addition
 // formulas: 15 sincos evaluations instead of 27, 12 of them on small arguments that need no range reduction.
-template <bool kWarm>
-__device__ __forceinline__ int propagate_fan(const double (&x)[4], const double (&P)[4][4], double scale, double dt,
-                                             double sr, double cr, double (&sig0)[9][4], double (&sig)[9][4],
-                                             EigBasis& basis) {
-    double T[4][4];
-    const int st = sym_sqrt4<kWarm>(P, scale, T, basis);
-    if (kWarm) basis.valid = true;
+__device__ __forceinline__ void propagate_fan_branching(const double (&x)[4], const double (&T)[4][4], double dt, double sr,
+                                                        double cr, double (&sig0)[9][4], double (&sig)[9][4]) {
     const double dt_r = dt / kEarthRadius;
     const double du = sr * dt, da = cr * dt;
     // centre
@@ -173,6 +168,80 @@ __device__ __forceinline__ int propagate_fan(const double (&x)[4], const double 
             sig[j][3] = (pt[3] * kDeg2Rad) * kRad2Deg + da;
         }
     }
+}
+
+// The same fan with the several-at-a-time, branch-free helpers of ste_math.h (each polynomial coefficient is fetched once
+// for the three angles of the centre, once per direction for its three increments, and once per direction for its +/-
+// pair); a wave in which some lane leaves their validity range redoes the step with the branching version above.
+__device__ __forceinline__ void propagate_points(const double (&x)[4], const double (&T)[4][4], double dt, double sr,
+                                                 double cr, double (&sig0)[9][4], double (&sig)[9][4]) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    const double dt_r = div_earth_radius(dt);
+
+    const double du = sr * dt, da = cr * dt;
+    bool ok = true;
+    const double lat0 = x[1] * kDeg2Rad, alpha0 = x[3] * kDeg2Rad, delta0 = x[2] * dt_r;
+    const double a0[3] = {lat0, alpha0, delta0};
+    double s_0[3], c_0[3];
+    sincos_fast_n<3>(a0, s_0, c_0, ok);
+    const double sp0 = s_0[0], cp0 = c_0[0], sa0 = s_0[1], ca0 = c_0[1], sd0 = s_0[2], cd0 = c_0[2];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) sig0[0][c] = x[c];
+    {
+        const double lo[1] = {x[0] * kDeg2Rad}, la[1] = {lat0}, vsp[1] = {sp0}, vcp[1] = {cp0}, vsa[1] = {sa0},
+                     vca[1] = {ca0}, vsd[1] = {sd0}, vcd[1] = {cd0};
+        double lon_o[1], lat_o[1];
+        geodetic_finish_n<1>(lo, la, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
+        sig[0][0] = lon_o[0];
+        sig[0][1] = lat_o[0];
+    }
+    sig[0][2] = x[2] + du;
+    sig[0][3] = fma(alpha0, kRad2Deg, da);
+    STE_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const double dl[3] = {T[1][i] * kDeg2Rad, T[3][i] * kDeg2Rad, T[2][i] * dt_r};
+        double s_d[3], c_d[3];
+        sincos_delta_n<3>(dl, s_d, c_d, ok);
+        const double p2 = cp0 * s_d[0], p4 = sp0 * s_d[0], a2 = ca0 * s_d[1], a4 = sa0 * s_d[1], d2 = cd0 * s_d[2],
+                     d4 = sd0 * s_d[2];
+        double ptp[4], ptm[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            ptp[c] = x[c] + T[c][i];
+            ptm[c] = x[c] - T[c][i];
+            sig0[1 + i][c] = ptp[c];
+            sig0[5 + i][c] = ptm[c];
+        }
+        const double lo[2] = {ptp[0] * kDeg2Rad, ptm[0] * kDeg2Rad}, la[2] = {ptp[1] * kDeg2Rad, ptm[1] * kDeg2Rad};
+        const double vsp[2] = {fma(sp0, c_d[0], p2), fma(sp0, c_d[0], -p2)};
+        const double vcp[2] = {fma(cp0, c_d[0], -p4), fma(cp0, c_d[0], p4)};
+        const double vsa[2] = {fma(sa0, c_d[1], a2), fma(sa0, c_d[1], -a2)};
+        const double vca[2] = {fma(ca0, c_d[1], -a4), fma(ca0, c_d[1], a4)};
+        const double vsd[2] = {fma(sd0, c_d[2], d2), fma(sd0, c_d[2], -d2)};
+        const double vcd[2] = {fma(cd0, c_d[2], -d4), fma(cd0, c_d[2], d4)};
+        double lon_o[2], lat_o[2];
+        geodetic_finish_n<2>(lo, la, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
+        sig[1 + i][0] = lon_o[0];
+        sig[1 + i][1] = lat_o[0];
+        sig[1 + i][2] = ptp[2] + du;
+        sig[1 + i][3] = fma(ptp[3] * kDeg2Rad, kRad2Deg, da);
+        sig[5 + i][0] = lon_o[1];
+        sig[5 + i][1] = lat_o[1];
+        sig[5 + i][2] = ptm[2] + du;
+        sig[5 + i][3] = fma(ptm[3] * kDeg2Rad, kRad2Deg, da);
+    }
+    if (__builtin_expect(__any(!ok), 0)) propagate_fan_branching(x, T, dt, sr, cr, sig0, sig);
+}
+
+
+template <bool kWarm>
+__device__ __forceinline__ int propagate_fan(const double (&x)[4], const double (&P)[4][4], double scale, double dt,
+                                             double sr, double cr, double (&sig0)[9][4], double (&sig)[9][4],
+                                             EigBasis& basis) {
+    double T[4][4];
+    const int st = sym_sqrt4<kWarm>(P, scale, T, basis);
+    if (kWarm) basis.valid = true;
+    propagate_points(x, T, dt, sr, cr, sig0, sig);
     return st;
 }
 

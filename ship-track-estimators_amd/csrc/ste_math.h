@@ -210,51 +210,55 @@ __device__ __forceinline__ void sincos_delta(double d, double& s, double& c) {
 // the rare failing case with the branching scalar functions above (same formulas, so lanes that were fine get the same
 // bits either way).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sincos_kernel3(const double (&r)[3], double (&s)[3], double (&c)[3]) {
-    double z[3], ps[3], pc[3];
+template <int N>
+__device__ __forceinline__ void sincos_kernel_n(const double (&r)[N], double (&s)[N], double (&c)[N]) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double z[N], ps[N], pc[N];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) z[i] = r[i] * r[i];
+    for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ps[i] = fma(z[i], ps[i], 2.75573137070700676789e-06);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], 2.75573137070700676789e-06);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ps[i] = fma(z[i], ps[i], -1.98412698298579493134e-04);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], -1.98412698298579493134e-04);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ps[i] = fma(z[i], ps[i], 8.33333333332248946124e-03);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], 8.33333333332248946124e-03);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ps[i] = fma(z[i], ps[i], -1.66666666666666324348e-01);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], -1.66666666666666324348e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s[i] = fma(z[i] * r[i], ps[i], r[i]);
+    for (int i = 0; i < N; ++i) s[i] = fma(z[i] * r[i], ps[i], r[i]);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pc[i] = fma(z[i], pc[i], -2.75573143513906633035e-07);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], -2.75573143513906633035e-07);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pc[i] = fma(z[i], pc[i], 2.48015872894767294178e-05);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], 2.48015872894767294178e-05);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pc[i] = fma(z[i], pc[i], -1.38888888888741095749e-03);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], -1.38888888888741095749e-03);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pc[i] = fma(z[i], pc[i], 4.16666666666666019037e-02);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], 4.16666666666666019037e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) c[i] = fma(z[i] * z[i], pc[i], fma(-0.5, z[i], 1.0));
+    for (int i = 0; i < N; ++i) c[i] = fma(z[i] * z[i], pc[i], fma(-0.5, z[i], 1.0));
 }
 
-// sincos_fast for three arguments; ok &= every |x| < 2^20
-__device__ __forceinline__ void sincos_fast3(const double (&x)[3], double (&s)[3], double (&c)[3], bool& ok) {
-    double n[3], r[3], sk[3], ck[3];
+// sincos_fast for N arguments; ok &= every |x| < 2^20
+template <int N>
+__device__ __forceinline__ void sincos_fast_n(const double (&x)[N], double (&s)[N], double (&c)[N], bool& ok) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double n[N], r[N], sk[N], ck[N];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         ok = ok && (fabs(x[i]) < 1048576.0);
         n[i] = rint(x[i] * 0.63661977236758134308);
     }
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) r[i] = fma(-n[i], 1.57079632679489655800e+00, x[i]);
+    for (int i = 0; i < N; ++i) r[i] = fma(-n[i], 1.57079632679489655800e+00, x[i]);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) r[i] = fma(-n[i], 6.12323399573676603587e-17, r[i]);
-    sincos_kernel3(r, sk, ck);
+    for (int i = 0; i < N; ++i) r[i] = fma(-n[i], 6.12323399573676603587e-17, r[i]);
+    sincos_kernel_n<N>(r, sk, ck);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int q = (int)n[i];
         const double sv = (q & 1) ? ck[i] : sk[i];
         const double cv = (q & 1) ? sk[i] : ck[i];
@@ -263,78 +267,86 @@ __device__ __forceinline__ void sincos_fast3(const double (&x)[3], double (&s)[3
     }
 }
 
-// sincos_delta for three arguments; ok &= every |d| <= pi/4
-__device__ __forceinline__ void sincos_delta3(const double (&d)[3], double (&s)[3], double (&c)[3], bool& ok) {
+// sincos_delta for N arguments; ok &= every |d| <= pi/4
+template <int N>
+__device__ __forceinline__ void sincos_delta_n(const double (&d)[N], double (&s)[N], double (&c)[N], bool& ok) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) ok = ok && (fabs(d[i]) <= 0.78539816339744828);
-    sincos_kernel3(d, s, c);
+    for (int i = 0; i < N; ++i) ok = ok && (fabs(d[i]) <= 0.78539816339744828);
+    sincos_kernel_n<N>(d, s, c);
 }
 
-__device__ __forceinline__ void atan_small3(const double (&q)[3], double (&out)[3]) {
-    double z[3], w[3], s1[3], s2[3];
+template <int N>
+__device__ __forceinline__ void atan_small_n(const double (&q)[N], double (&out)[N]) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double z[N], w[N], s1[N], s2[N];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         z[i] = q[i] * q[i];
         w[i] = z[i] * z[i];
     }
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s1[i] = fma(w[i], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s1[i] = fma(w[i], s1[i], 6.66107313738753120669e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 6.66107313738753120669e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s1[i] = fma(w[i], s1[i], 9.09088713343650656196e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 9.09088713343650656196e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s1[i] = fma(w[i], s1[i], 1.42857142725034663711e-01);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 1.42857142725034663711e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s1[i] = fma(w[i], s1[i], 3.33333333333329318027e-01);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 3.33333333333329318027e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s2[i] = fma(w[i], -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], -3.65315727442169155270e-02, -5.83357013379057348645e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s2[i] = fma(w[i], s2[i], -7.69187620504482999495e-02);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -7.69187620504482999495e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s2[i] = fma(w[i], s2[i], -1.11111104054623557880e-01);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -1.11111104054623557880e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) s2[i] = fma(w[i], s2[i], -1.99999999998764832476e-01);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -1.99999999998764832476e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) out[i] = fma(-q[i], fma(z[i], s1[i], w[i] * s2[i]), q[i]);
+    for (int i = 0; i < N; ++i) out[i] = fma(-q[i], fma(z[i], s1[i], w[i] * s2[i]), q[i]);
 }
 
-__device__ __forceinline__ void asin_small3(const double (&x)[3], double (&out)[3]) {
-    double t[3], pn[3], qd[3];
+template <int N>
+__device__ __forceinline__ void asin_small_n(const double (&x)[N], double (&out)[N]) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double t[N], pn[N], qd[N];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) t[i] = x[i] * x[i];
+    for (int i = 0; i < N; ++i) t[i] = x[i] * x[i];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] = fma(t[i], 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], 3.47933107596021167570e-05, 7.91534994289814532176e-04);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] = fma(t[i], pn[i], -4.00555345006794114027e-02);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], -4.00555345006794114027e-02);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] = fma(t[i], pn[i], 2.01212532134862925881e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], 2.01212532134862925881e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] = fma(t[i], pn[i], -3.25565818622400915405e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], -3.25565818622400915405e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] = fma(t[i], pn[i], 1.66666666666666657415e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], 1.66666666666666657415e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) pn[i] *= t[i];
+    for (int i = 0; i < N; ++i) pn[i] *= t[i];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) qd[i] = fma(t[i], 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], 7.70381505559019352791e-02, -6.88283971605453293030e-01);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) qd[i] = fma(t[i], qd[i], 2.02094576023350569471e+00);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], 2.02094576023350569471e+00);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) qd[i] = fma(t[i], qd[i], -2.40339491173441421878e+00);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], -2.40339491173441421878e+00);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) qd[i] = fma(t[i], qd[i], 1.0);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], 1.0);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) out[i] = fma(x[i], div_pos(pn[i], qd[i]), x[i]);
+    for (int i = 0; i < N; ++i) out[i] = fma(x[i], div_pos(pn[i], qd[i]), x[i]);
 }
 
-// geodetic_finish for three points; ok &= the fast atan2 / asin paths apply to all of them
-__device__ __forceinline__ void geodetic_finish3(const double (&lon_r)[3], const double (&lat_r)[3], const double (&sp)[3],
-                                                 const double (&cp)[3], const double (&sa)[3], const double (&ca)[3],
-                                                 const double (&sd)[3], const double (&cd)[3], double (&lon_out)[3],
-                                                 double (&lat_out)[3], bool& ok) {
-    double a[3], b[3], sl[3], h2[3], xs[3], qa[3], at[3], as[3];
+// geodetic_finish for N points; ok &= the fast atan2 / asin paths apply to all of them
+template <int N>
+__device__ __forceinline__ void geodetic_finish_n(const double (&lon_r)[N], const double (&lat_r)[N], const double (&sp)[N],
+                                                  const double (&cp)[N], const double (&sa)[N], const double (&ca)[N],
+                                                  const double (&sd)[N], const double (&cd)[N], double (&lon_out)[N],
+                                                  double (&lat_out)[N], bool& ok) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double a[N], b[N], sl[N], h2[N], xs[N], qa[N], at[N], as[N];
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         a[i] = sd[i] * sa[i];
         const double sdca = sd[i] * ca[i];
         b[i] = fma(cp[i], cd[i], -(sp[i] * sdca));
@@ -343,17 +355,17 @@ __device__ __forceinline__ void geodetic_finish3(const double (&lon_r)[3], const
         h2[i] = fma(a[i], a[i], b[i] * b[i]);
     }
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) qa[i] = div_pos(a[i], b[i]);
-    atan_small3(qa, at);
+    for (int i = 0; i < N; ++i) qa[i] = div_pos(a[i], b[i]);
+    atan_small_n<N>(qa, at);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         const double cl = h2[i] * rsqrt_fast(h2[i]);
         xs[i] = fma(sl[i], cp[i], -(cl * sp[i]));
         ok = ok && (fabs(xs[i]) <= 0.5) && (h2[i] > 1e-300);
     }
-    asin_small3(xs, as);
+    asin_small_n<N>(xs, as);
     STE_UNROLL
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < N; ++i) {
         lon_out[i] = (lon_r[i] + at[i]) * kRad2Deg;
         lat_out[i] = (lat_r[i] + as[i]) * kRad2Deg;
     }

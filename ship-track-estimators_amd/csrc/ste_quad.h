@@ -384,20 +384,21 @@ __device__ __forceinline__ void quad_propagate_branching(const double (&x)[4], c
 // leaves their validity range (a pole, a giant step, non-finite data) redoes the step with the branching version.
 __device__ __forceinline__ void quad_propagate(const double (&x)[4], const double (&Tn)[4], double dt, double sr,
                                                double cr, double (&s0)[4], double (&sp)[4], double (&sm)[4]) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     const double dt_r = div_earth_radius(dt);
     const double du = sr * dt, da = cr * dt;
     const double lat0 = x[1] * kDeg2Rad, alpha0 = x[3] * kDeg2Rad, delta0 = x[2] * dt_r;
     bool ok = true;
     const double a0[3] = {lat0, alpha0, delta0};
     double s_0[3], c_0[3];
-    sincos_fast3(a0, s_0, c_0, ok);
+    sincos_fast_n<3>(a0, s_0, c_0, ok);
     const double dl[3] = {Tn[1] * kDeg2Rad, Tn[3] * kDeg2Rad, Tn[2] * dt_r};
     double s_d[3], c_d[3];
-    sincos_delta3(dl, s_d, c_d, ok);
+    sincos_delta_n<3>(dl, s_d, c_d, ok);
     const double sp0 = s_0[0], cp0 = c_0[0], sa0 = s_0[1], ca0 = c_0[1], sd0 = s_0[2], cd0 = c_0[2];
-    const double p1 = sp0 * c_d[0], p2 = cp0 * s_d[0], p3 = cp0 * c_d[0], p4 = sp0 * s_d[0];
-    const double a1 = sa0 * c_d[1], a2 = ca0 * s_d[1], a3 = ca0 * c_d[1], a4 = sa0 * s_d[1];
-    const double d1 = sd0 * c_d[2], d2 = cd0 * s_d[2], d3 = cd0 * c_d[2], d4 = sd0 * s_d[2];
+    // angle addition for the +/- pair: sin(a +- d) = sin a cos d +- cos a sin d, cos(a +- d) = cos a cos d -+ sin a sin d
+    const double p2 = cp0 * s_d[0], p4 = sp0 * s_d[0], a2 = ca0 * s_d[1], a4 = sa0 * s_d[1], d2 = cd0 * s_d[2],
+                 d4 = sd0 * s_d[2];
     double ptp[4], ptm[4];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
@@ -406,11 +407,14 @@ __device__ __forceinline__ void quad_propagate(const double (&x)[4], const doubl
     }
     const double lon_r[3] = {x[0] * kDeg2Rad, ptp[0] * kDeg2Rad, ptm[0] * kDeg2Rad};
     const double lat_r[3] = {lat0, ptp[1] * kDeg2Rad, ptm[1] * kDeg2Rad};
-    const double vsp[3] = {sp0, p1 + p2, p1 - p2}, vcp[3] = {cp0, p3 - p4, p3 + p4};
-    const double vsa[3] = {sa0, a1 + a2, a1 - a2}, vca[3] = {ca0, a3 - a4, a3 + a4};
-    const double vsd[3] = {sd0, d1 + d2, d1 - d2}, vcd[3] = {cd0, d3 - d4, d3 + d4};
+    const double vsp[3] = {sp0, fma(sp0, c_d[0], p2), fma(sp0, c_d[0], -p2)};
+    const double vcp[3] = {cp0, fma(cp0, c_d[0], -p4), fma(cp0, c_d[0], p4)};
+    const double vsa[3] = {sa0, fma(sa0, c_d[1], a2), fma(sa0, c_d[1], -a2)};
+    const double vca[3] = {ca0, fma(ca0, c_d[1], -a4), fma(ca0, c_d[1], a4)};
+    const double vsd[3] = {sd0, fma(sd0, c_d[2], d2), fma(sd0, c_d[2], -d2)};
+    const double vcd[3] = {cd0, fma(cd0, c_d[2], -d4), fma(cd0, c_d[2], d4)};
     double lon_o[3], lat_o[3];
-    geodetic_finish3(lon_r, lat_r, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
+    geodetic_finish_n<3>(lon_r, lat_r, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
     if (__builtin_expect(__any(!ok), 0)) {
         quad_propagate_branching(x, Tn, dt, sr, cr, s0, sp, sm);
         return;
@@ -418,15 +422,15 @@ __device__ __forceinline__ void quad_propagate(const double (&x)[4], const doubl
     s0[0] = lon_o[0];
     s0[1] = lat_o[0];
     s0[2] = x[2] + du;
-    s0[3] = alpha0 * kRad2Deg + da;
+    s0[3] = fma(alpha0, kRad2Deg, da);
     sp[0] = lon_o[1];
     sp[1] = lat_o[1];
     sp[2] = ptp[2] + du;
-    sp[3] = (ptp[3] * kDeg2Rad) * kRad2Deg + da;
+    sp[3] = fma(ptp[3] * kDeg2Rad, kRad2Deg, da);
     sm[0] = lon_o[2];
     sm[1] = lat_o[2];
     sm[2] = ptm[2] + du;
-    sm[3] = (ptm[3] * kDeg2Rad) * kRad2Deg + da;
+    sm[3] = fma(ptm[3] * kDeg2Rad, kRad2Deg, da);
 }
 
 }  // namespace ste
