@@ -1287,9 +1287,9 @@ int g_lanes_per_track = 0;  // 0 = automatic
 // as many waves on the chip, but replicates work across its lanes and -- at 362 VGPRs -- runs one wave per SIMD, so
 // beyond 16 384 tracks (1 024 waves) the launch takes a second round.  Measured on MI355X, forward + smoother:
 //   tracks      12 288   16 384   20 480   32 768   40 960
-//   quad  ms      4.11     4.65     8.16     9.01    12.85
-//   lane  ms      7.51     7.71     8.47     9.29    10.09
-constexpr int kQuadMaxTracks = 32768;
+//   quad  ms      3.78     4.35     7.58     8.41    11.97
+//   lane  ms      5.65     5.84     6.54     7.29     8.23
+constexpr int kQuadMaxTracks = 16384;
 int choose_lanes(int B, bool robust) {
     if (robust) return 1;  // the robust update exists in the lane-per-track kernels only
     if (g_lanes_per_track == 1 || g_lanes_per_track == 4) return g_lanes_per_track;
