@@ -256,6 +256,38 @@ __device__ __forceinline__ int quad_sym_sqrt(const double (&Px)[4], double scale
 
 // Row q (natural order) of pinv(S) for a symmetric S given as natural-order rows (np.linalg.pinv cutoff, unscented.py:243).
 __device__ __forceinline__ int quad_sym_pinv(const double (&Sn)[4], const QuadCtx& cx, double (&Sin)[4]) {
+    // Fast path: S = H P H^T + R with an H that observes two components (the reference's H = diag(1, 1, 0, 0)) is zero
+    // outside its leading 2 x 2 block.  Its eigen-decomposition is then ONE exact rotation, evaluated on every lane with
+    // the formulas of quad_jacobi_round, instead of a three-round sweep plus a confirming pass over a 4 x 4 matrix that
+    // is three quarters zeros.  Taken only when every track of the wave has that structure.
+    {
+        const int q = cx.q;
+        const bool blk = (q < 2) ? (Sn[2] == 0.0 && Sn[3] == 0.0)
+                                 : (Sn[0] == 0.0 && Sn[1] == 0.0 && Sn[2] == 0.0 && Sn[3] == 0.0);
+        if (__all(blk)) {
+            const double a = bcast<0>(Sn[0]), d = bcast<1>(Sn[1]);
+            const double b = 0.5 * (bcast<0>(Sn[1]) + bcast<1>(Sn[0]));
+            const bool go = b * b > kRotTol2 * fabs(a * d);
+            const double delta = d - a, two_b = b + b;
+            const double rh = rsqrt_fast(go ? fma(delta, delta, two_b * two_b) : 1.0);
+            const double c2 = fma(0.5 * fabs(delta), rh, 0.5);
+            const double rc = rsqrt_fast(c2);
+            const double c = go ? c2 * rc : 1.0;
+            const double sn = go ? (delta < 0.0 ? -b : b) * rh * rc : 0.0;
+            const double tb = go ? sn * rc * b : 0.0;
+            const double w0 = a - tb, w1 = d + tb;
+            const double cutoff = kPinvRcond * fmax(fabs(w0), fabs(w1));
+            const double f0 = (fabs(w0) > cutoff) ? 1.0 / w0 : 0.0, f1 = (fabs(w1) > cutoff) ? 1.0 / w1 : 0.0;
+            // pinv = V diag(f) V^T with V = [[c, s], [-s, c]]
+            const double cc = c * c, ss = sn * sn, cs = c * sn;
+            const double i00 = fma(cc, f0, ss * f1), i11 = fma(ss, f0, cc * f1), i01 = cs * (f1 - f0);
+            Sin[0] = (q == 0) ? i00 : (q == 1 ? i01 : 0.0);
+            Sin[1] = (q == 0) ? i01 : (q == 1 ? i11 : 0.0);
+            Sin[2] = 0.0;
+            Sin[3] = 0.0;
+            return 0;
+        }
+    }
     double A[4], V[4] = {1.0, 0.0, 0.0, 0.0};
     xorperm(Sn, cx.q, A);
     // symmetrise like sym_pinv4: average with the transposed entry held by the partner lanes
