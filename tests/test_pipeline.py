@@ -63,3 +63,37 @@ def test_pipeline_hooks_and_timing_events():
     assert float((dbs[0].sm_mean - ref).abs().max() / ref.abs().max()) < 1e-10
     assert dbs[0].struct.flags & 0x8 == 0  # the flag is not left behind on the batch
     pipe.close()
+
+
+def test_pipeline_full_size_matches_serial():
+    """BASELINE.json configs[1] at full size (10 000 tracks x 500 steps): six pipelined steps over two sets of buffers
+    leave exactly the bits one batch run on its own leaves; with the lane-per-track recurrence on the smoother partition
+    (what bench.py uses) the smoothed states agree to rounding."""
+    import torch
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(10_000, nobs=126, gap_h=1.0, seed0=31)
+    hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    ref = batch.DeviceBatch(hb)
+    ref.run()
+    torch.cuda.synchronize()
+    dbs = [batch.DeviceBatch(hb), batch.DeviceBatch(hb)]
+    pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
+    assert (pipe.forward_cus, pipe.smoother_cus) == (160, 96)
+    for k in range(6):
+        pipe.submit(dbs[k & 1], final=(k == 5))
+    pipe.synchronize()
+    for db in dbs:
+        assert torch.equal(db.fwd_mean, ref.fwd_mean) and torch.equal(db.fwd_cov, ref.fwd_cov)
+        assert torch.equal(db.sm_mean, ref.sm_mean) and torch.equal(db.sm_cov, ref.sm_cov)
+        assert not db.status_host().any()
+    pipe.close()
+    pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B, smoother_lane_per_track=True)
+    for k in range(4):
+        pipe.submit(dbs[k & 1], final=(k == 3))
+    pipe.synchronize()
+    for db in dbs:
+        assert torch.equal(db.fwd_mean, ref.fwd_mean)
+        err = (db.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
+        assert float(err.max()) < 1e-9
+    pipe.close()
