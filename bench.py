@@ -15,9 +15,10 @@ Prints ONE JSON line on rank 0.  Extra objects:
                 (one process, and one forked worker per core of the box's CPU share)
   serial        the same work without overlapping consecutive steps (see --no-pipeline), for the record
 
-Steps are pipelined by default: every step runs the complete forward pass and smoother of one 10 000-track batch, but the
-smoother of step i (latency-bound, 96 CUs) runs beside the forward pass of step i+1 (625 long-running waves, 160 CUs) on
-CU-masked streams, with two sets of history buffers used alternately (track_estimators.batch.SmootherPipeline).
+Steps are pipelined by default: every step runs the complete forward pass and smoother of one 10 000-track batch, but up
+to four steps are in flight -- two forward passes (625 long-running waves each, two waves per SIMD) on 160 CUs and the two
+smoothers before them (latency-bound) on the other 96, on CU-masked streams, with five sets of history buffers in rotation
+(track_estimators.batch.SmootherPipeline).
 """
 import argparse
 import json
@@ -104,7 +105,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="tracks per GPU")
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
@@ -162,9 +163,9 @@ def main():
     sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=rank * B)
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     db = batch.DeviceBatch(hb, device=dev)
-    # Pipelined mode (default): two sets of histories used alternately; the forward pass of step i+1 runs on the first
-    # 160 CUs while the smoother of step i runs on the other 96 (batch.SmootherPipeline).  Every step still does the
-    # whole forward + smoother of one batch; nothing is skipped, the steps overlap.
+    # Pipelined mode (default): five sets of histories in rotation; two forward passes at a time share the first 160 CUs
+    # (two waves per SIMD) while the smoothers of the two steps before them share the other 96 (batch.SmootherPipeline).
+    # Every step still does the whole forward + smoother of one batch; nothing is skipped, the steps overlap.
     pipe = None
     if not args.no_pipeline:
         try:
@@ -174,7 +175,7 @@ def main():
             pipe = batch.SmootherPipeline(dev, ntracks=B, smoother_lane_per_track=True)
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
-    dbs = [db] if pipe is None else [db, batch.DeviceBatch(hb, device=dev)]
+    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev) for _ in range(pipe.buffers_needed - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
@@ -281,9 +282,10 @@ def main():
                 "tracks_per_gpu": B, "steps_per_track": int(hb.Nmax), "observations": NOBS, "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (", RCCL all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
-                             f"smoother of step i on {pipe.smoother_cus} CUs beside the forward pass of step i+1 on "
-                             f"{pipe.forward_cus} CUs (CU-masked streams, two sets of histories used alternately, lane-per-track "
-                             "recurrence on the smoother partition)"),
+                             f"{len(pipe.fwd_streams)} forward passes in flight on {pipe.forward_cus} CUs (two waves per "
+                             f"SIMD) beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked "
+                             f"streams, {len(dbs)} sets of histories in rotation, lane-per-track recurrence on the smoother "
+                             "partition)"),
                 "lanes_per_track": int(lib.ste_set_lanes_per_track(args.lanes)),
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},

@@ -375,24 +375,27 @@ class DeviceBatch:
 
 class SmootherPipeline:
     """
-    Forward passes and smoothers of consecutive batches on disjoint halves of the GPU.
+    Forward passes and smoothers of consecutive batches on disjoint parts of the GPU, several in flight.
 
     A batch of BASELINE size (10 000 tracks) is 625 long-running forward waves on 1 024 SIMDs followed by a
     latency-bound smoother.  Run back to back they leave most of the chip idle; run side by side on ordinary streams
-    they land on the same SIMDs and take each other's issue slots.  Here the forward pass of batch i+1 runs on a stream
-    restricted to the first ``forward_cus`` compute units and the smoother of batch i on a stream restricted to the rest
-    (``ste_stream_create_cu_range``), so the smoother disappears behind the next forward pass.  Each ``DeviceBatch``
-    owns its histories and work rows, so two or more of them can be in flight; a batch is not resubmitted before its
-    previous smoother has finished (tracked with events).
+    they land on the same SIMDs and take each other's issue slots.  Here forward passes run on streams restricted to
+    the first ``forward_cus`` compute units and smoothers on streams restricted to the rest
+    (``ste_stream_create_cu_range``).  The forward kernel needs at most 256 VGPRs, so two forward passes share the
+    forward partition with two waves per SIMD -- a lone wave can use only half of the fp64 pipe's issue slots -- and the
+    smoothers of two batches share the smoother partition, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
+    its histories and work rows; a batch is not resubmitted before its previous smoother has finished (events), so the
+    caller rotates through ``depth + 1`` or more of them (``buffers_needed``).
 
         pipe = SmootherPipeline(device)
-        for db in device_batches:        # e.g. two DeviceBatch objects used alternately
-            pipe.submit(db)
+        dbs = [DeviceBatch(hb, device) for _ in range(pipe.buffers_needed)]
+        for k in range(nbatches):
+            pipe.submit(dbs[k % len(dbs)], final=(k == nbatches - 1))
         pipe.synchronize()
     """
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
-                 smoother_lane_per_track: bool = False):
+                 smoother_lane_per_track: bool = False, forward_streams: int = 2, smoother_streams: int = 2):
         import torch
 
         self.torch = torch
@@ -401,50 +404,67 @@ class SmootherPipeline:
         self.device = torch.device(device)
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
         if forward_cus is None:
-            # room for every forward wave of an ``ntracks`` batch (a quad per track, one wave per SIMD), counted per
+            # room for every forward wave of an ``ntracks`` batch at one wave per SIMD (a quad per track), counted per
             # XCD because workgroups are dealt round-robin over the 8 XCDs; default: BASELINE's 10 000 tracks
             waves = -(-(ntracks or 10_000) * 4 // 64)
             forward_cus = 8 * -(-(-(-waves // 8)) // 4)
         if not (0 < forward_cus < ncu):
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
+        if forward_streams < 1 or smoother_streams < 1:
+            raise ValueError("forward_streams and smoother_streams must be >= 1")
         self.forward_cus, self.smoother_cus = int(forward_cus), int(ncu - forward_cus)
+        self._raw = []
+        self.fwd_streams, self.bwd_streams = [], []
         with torch.cuda.device(self.device):
-            raw = []
-            for first, count in ((0, self.forward_cus), (self.forward_cus, self.smoother_cus)):
-                h = C.c_void_p()
-                binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)), "ste_stream_create_cu_range")
-                raw.append(h)
-        self._raw = raw
+            for first, count, n, out in ((0, self.forward_cus, forward_streams, self.fwd_streams),
+                                         (self.forward_cus, self.smoother_cus, smoother_streams, self.bwd_streams)):
+                for _ in range(n):
+                    h = C.c_void_p()
+                    binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)),
+                                  "ste_stream_create_cu_range")
+                    self._raw.append(h)
+                    out.append(torch.cuda.ExternalStream(h.value, device=self.device))
         self._tail_stream = None
-        self.fwd_stream = torch.cuda.ExternalStream(raw[0].value, device=self.device)
-        self.bwd_stream = torch.cuda.ExternalStream(raw[1].value, device=self.device)
+        self._count = 0
+        self.buffers_needed = forward_streams + smoother_streams + 1
+
+    # single-stream names kept for callers that look at them
+    @property
+    def fwd_stream(self):
+        return self.fwd_streams[0]
+
+    @property
+    def bwd_stream(self):
+        return self.bwd_streams[0]
 
     def submit(self, db: "DeviceBatch", after_smoother=None, timing=None, final: bool = False):
         """Queue forward + smoother of ``db``; returns the event that marks its smoother (and ``after_smoother``) done.
 
         ``after_smoother(stream)``: optional callable run with the smoother stream current, right after the smoother
         kernels are queued (the multi-GPU driver starts its all-gather of the smoothed positions there).
-        ``timing``: optional list of four timing-enabled events, recorded before / after the forward kernel on the
-        forward stream and before / after the smoother kernels on the smoother stream.
+        ``timing``: optional list of four timing-enabled events, recorded before / after the forward kernel on its
+        forward stream and before / after the smoother kernels on its smoother stream.
         ``final``: nothing follows this batch, so its smoother gets an unrestricted stream (the whole chip) instead of the
         smoother partition."""
         torch = self.torch
-        bwd_stream = self.bwd_stream
+        k = self._count
+        self._count += 1
+        fwd_stream = self.fwd_streams[k % len(self.fwd_streams)]
+        bwd_stream = self.bwd_streams[k % len(self.bwd_streams)]
         if final:
             if self._tail_stream is None:
                 self._tail_stream = torch.cuda.Stream(self.device)
             bwd_stream = self._tail_stream
-            bwd_stream.wait_stream(self.bwd_stream)  # smoothers queued earlier stay ahead of this one
         done = getattr(db, "_pipeline_done", None)
         if done is not None:
-            self.fwd_stream.wait_event(done)  # the previous use of these buffers has drained
+            fwd_stream.wait_event(done)  # the previous use of these buffers has drained
         else:
-            self.fwd_stream.wait_stream(torch.cuda.current_stream(self.device))  # uploads queued by the constructor
+            fwd_stream.wait_stream(torch.cuda.current_stream(self.device))  # uploads queued by the constructor
         if timing is not None:
-            timing[0].record(self.fwd_stream)
-        db.forward(self.fwd_stream)
+            timing[0].record(fwd_stream)
+        db.forward(fwd_stream)
         ready = timing[1] if timing is not None else torch.cuda.Event()
-        ready.record(self.fwd_stream)
+        ready.record(fwd_stream)
         bwd_stream.wait_event(ready)
         if timing is not None:
             timing[2].record(bwd_stream)
@@ -466,14 +486,12 @@ class SmootherPipeline:
                 after_smoother(bwd_stream)
         done = torch.cuda.Event()
         done.record(bwd_stream)
-        if final:
-            self.bwd_stream.wait_event(done)  # later submissions' smoothers queue up behind this one again
         db._pipeline_done = done
         return done
 
     def synchronize(self):
-        self.fwd_stream.synchronize()
-        self.bwd_stream.synchronize()
+        for s in self.fwd_streams + self.bwd_streams:
+            s.synchronize()
         if self._tail_stream is not None:
             self._tail_stream.synchronize()
 
@@ -481,7 +499,7 @@ class SmootherPipeline:
         for h in self._raw:
             if h is not None and h.value:
                 self.lib.ste_stream_destroy(h)
-        self._raw = [None, None]
+        self._raw = []
 
 
 def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: str = "wgs84", device="cuda:0"):

@@ -77,11 +77,11 @@ def test_pipeline_full_size_matches_serial():
     ref = batch.DeviceBatch(hb)
     ref.run()
     torch.cuda.synchronize()
-    dbs = [batch.DeviceBatch(hb), batch.DeviceBatch(hb)]
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert (pipe.forward_cus, pipe.smoother_cus) == (160, 96)
-    for k in range(6):
-        pipe.submit(dbs[k & 1], final=(k == 5))
+    assert (pipe.forward_cus, pipe.smoother_cus) == (160, 96) and pipe.buffers_needed == 5
+    dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
+    for k in range(8):
+        pipe.submit(dbs[k % 3], final=(k == 7))
     pipe.synchronize()
     for db in dbs:
         assert torch.equal(db.fwd_mean, ref.fwd_mean) and torch.equal(db.fwd_cov, ref.fwd_cov)
@@ -89,8 +89,8 @@ def test_pipeline_full_size_matches_serial():
         assert not db.status_host().any()
     pipe.close()
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B, smoother_lane_per_track=True)
-    for k in range(4):
-        pipe.submit(dbs[k & 1], final=(k == 3))
+    for k in range(6):
+        pipe.submit(dbs[k % 3], final=(k == 5))
     pipe.synchronize()
     for db in dbs:
         assert torch.equal(db.fwd_mean, ref.fwd_mean)
