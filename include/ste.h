@@ -298,7 +298,8 @@ int ste_stream_destroy(void* stream);
 
 /*
  * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
- *   0 = automatic (a quad per track up to 16 384 tracks per launch, a lane per track above),
+ *   0 = automatic (forward pass: a quad per track up to 32 768 tracks per launch; smoother recurrence: up to 16 384;
+ *       a lane per track above),
  *   1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
  * Returns the previous value.  Process-global; not part of the reference-facing surface.
  */

@@ -1288,16 +1288,19 @@ namespace {
 thread_local char g_err[512] = "";
 int g_lanes_per_track = 0;  // 0 = automatic
 // Lane mapping of the sequential kernels.  A quad per track shortens the per-wave instruction stream ~1.7x and puts 4x
-// as many waves on the chip, but replicates work across its lanes and -- at 362 VGPRs -- runs one wave per SIMD, so
-// beyond 16 384 tracks (1 024 waves) the launch takes a second round.  Measured on MI355X, forward + smoother:
-//   tracks      12 288   16 384   20 480   32 768   40 960
-//   quad  ms      3.78     4.35     7.58     8.41    11.97
-//   lane  ms      5.65     5.84     6.54     7.29     8.23
-constexpr int kQuadMaxTracks = 16384;
-int choose_lanes(int B, bool robust) {
+// as many waves on the chip, but replicates work across its lanes.  The quad forward kernel fits two waves on a SIMD
+// (<= 256 VGPRs), so it stays a single round up to 32 768 tracks (2 048 waves); the quad recurrence of the smoother
+// (264 VGPRs, one wave per SIMD) only up to 16 384, after which the lane-per-track recurrence takes over.
+// Measured on MI355X, forward + smoother, ms:
+//   tracks                     12 288   16 384   20 480   32 768   40 960
+//   quad forward + quad smoother 3.71     4.23     6.47     7.38    10.41
+//   lane forward + lane smoother 5.65     5.85     6.52     7.29     8.29
+constexpr int kQuadMaxTracks = 32768;          // forward pass
+constexpr int kQuadSmootherMaxTracks = 16384;  // smoother recurrence
+int choose_lanes(int B, bool robust, bool smoother = false) {
     if (robust) return 1;  // the robust update exists in the lane-per-track kernels only
     if (g_lanes_per_track == 1 || g_lanes_per_track == 4) return g_lanes_per_track;
-    return B <= kQuadMaxTracks ? 4 : 1;
+    return B <= (smoother ? kQuadSmootherMaxTracks : kQuadMaxTracks) ? 4 : 1;
 }
 
 int fail(int code, const char* fmt, const char* detail = "") {
@@ -1393,7 +1396,7 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
             int rc = check_hip(hipGetLastError(), "urtss_gain launch");
             if (rc) return rc;
         }
-        if (!(kp.flags & STE_FLAG_SMOOTHER_LANE_PER_TRACK) && choose_lanes(kp.B, false) == 4) {
+        if (!(kp.flags & STE_FLAG_SMOOTHER_LANE_PER_TRACK) && choose_lanes(kp.B, false, true) == 4) {
             const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
             hipLaunchKernelGGL(ste::urtss_combine_q4, dim3(gridq), dim3(64), 0, s, kp);
         } else {
