@@ -301,6 +301,57 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         __syncthreads();
     }
 }
+// The same contraction in at most 256 VGPRs, for kernels that run two workgroups per CU (two waves per SIMD): two
+// rotating fragment sets instead of four, the shared fragments read one block row at a time, the staged panel held in
+// two halves.  Each wave prefetches less far ahead, but the second wave on the SIMD keeps the MFMA pipe busy meanwhile.
+__device__ __forceinline__ void mma_sub_lean(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const v4d a = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], own.v[n][e], acc[m][n], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_half(double* dst, const double* src, size_t ld, int tid, int half) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 256 * (2 * half + q);
+        const v4d v = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 4);
+        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -v;
+    }
+}
+__device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
+                                                  const double* const (&own)[4], int kb0, int kb1, double* stage, int tid,
+                                                  int lane) {
+    if (kb0 >= kb1) return;
+    const int r = lane & 15, g = lane >> 4;
+    stage_half(stage, shared + (size_t)kb0 * T, lds_ld, tid, 0);
+    stage_half(stage, shared + (size_t)kb0 * T, lds_ld, tid, 1);
+    RowFrag f0, f1;
+    load_rows(f0, own, kb0 * T);
+    load_rows(f1, own, kb0 * T + 16);
+    __syncthreads();
+    for (int kb = kb0; kb < kb1; ++kb) {
+        double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
+        double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
+        const int kn = (kb + 1 < kb1 ? kb + 1 : kb0) * T;  // refills past the end re-read the first block and are dropped
+        mma_sub_lean(acc, cur, 0, f0, r, g);
+        load_rows(f0, own, kb * T + 32);
+        stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 0);
+        mma_sub_lean(acc, cur, 1, f1, r, g);
+        load_rows(f1, own, kb * T + 48);
+        mma_sub_lean(acc, cur, 2, f0, r, g);
+        load_rows(f0, own, kn);
+        stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 1);
+        mma_sub_lean(acc, cur, 3, f1, r, g);
+        load_rows(f1, own, kn + 16);
+        __syncthreads();
+    }
+}
+
 // For m2 = 0..3: row[n] = sum_m sum_e Dl[16 m2 + r][16 m + 4 e + g] * in[m][n][e], handed to f(m2, row) one block row at
 // a time so that only four result tiles are live (Dl: 64 x 64 in LDS, leading dimension LD).
 template <typename F>
@@ -515,7 +566,7 @@ __host__ __device__ inline int kinv_strips(int nb) {  // strips of a matrix with
     return s;
 }
 
-__global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* kinv_out) {
+__global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double* kinv_out) {
     __shared__ double red[3][4];
     __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
     // XCD-aware mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with a
@@ -551,7 +602,7 @@ __global__ __launch_bounds__(256) void gp_kinv_trace(const GpParams p, double* k
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) acc[m][nn] = v4d{0.0, 0.0, 0.0, 0.0};
-    panel_gemm_t(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, ta, stage, tid, lane);
+    panel_gemm_t_lean(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, stage, tid, lane);
     // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = tb*64 + 16 nn + r (own rows)
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     const double* x = p.x + (size_t)b * p.nmax;
