@@ -21,6 +21,7 @@ smoothers before them (latency-bound) on the other 96, on CU-masked streams, wit
 (track_estimators.batch.SmootherPipeline).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -102,6 +103,12 @@ def cpu_baseline_pool(procs: int, tracks_per_proc: int):
 
 
 def main():
+    # the pipeline's CU-masked streams are destroyed before the interpreter goes down, whatever happens in between
+    with contextlib.ExitStack() as stack:
+        _main(stack)
+
+
+def _main(stack):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -172,7 +179,7 @@ def main():
             # lane-per-track recurrence on the smoother partition: 1.95 instead of 2.39 ms there, which keeps the smoother
             # off the critical path now that the forward pass takes 2.38 ms (results differ from the quad recurrence
             # by rounding, ~1e-13; the oracle cross-check below covers them)
-            pipe = batch.SmootherPipeline(dev, ntracks=B, smoother_lane_per_track=True)
+            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=B, smoother_lane_per_track=True))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
     dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev) for _ in range(pipe.buffers_needed - 1)]

@@ -14,8 +14,10 @@ Reference call sites replaced (relative to /root/reference):
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import dataclasses
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -415,18 +417,28 @@ class SmootherPipeline:
         self.forward_cus, self.smoother_cus = int(forward_cus), int(ncu - forward_cus)
         self._raw = []
         self.fwd_streams, self.bwd_streams = [], []
-        with torch.cuda.device(self.device):
-            for first, count, n, out in ((0, self.forward_cus, forward_streams, self.fwd_streams),
-                                         (self.forward_cus, self.smoother_cus, smoother_streams, self.bwd_streams)):
-                for _ in range(n):
-                    h = C.c_void_p()
-                    binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)),
-                                  "ste_stream_create_cu_range")
-                    self._raw.append(h)
-                    out.append(torch.cuda.ExternalStream(h.value, device=self.device))
         self._tail_stream = None
         self._count = 0
+        self._batches = []  # weak references to the DeviceBatches that carry one of this pipeline's events
         self.buffers_needed = forward_streams + smoother_streams + 1
+        try:
+            with torch.cuda.device(self.device):
+                for first, count, n, out in ((0, self.forward_cus, forward_streams, self.fwd_streams),
+                                             (self.forward_cus, self.smoother_cus, smoother_streams, self.bwd_streams)):
+                    for _ in range(n):
+                        h = C.c_void_p()
+                        binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)),
+                                      "ste_stream_create_cu_range")
+                        self._raw.append(h)
+                        out.append(torch.cuda.ExternalStream(h.value, device=self.device))
+        except BaseException:
+            self.close()  # do not leak the streams created before the failing one
+            raise
+        # CU-masked streams own HSA queues of their own.  Left alive until the process exits they are torn down by the
+        # HIP runtime's static destructors, after Python, torch and any profiler tool have finalised -- under rocprofv3
+        # that order ended every pipelined run of round 1 in a SIGSEGV inside __cxa_finalize.  So the streams are
+        # destroyed while everything is still up: close() / the context manager / __del__, and at the latest atexit.
+        _live_pipelines.add(self)
 
     # single-stream names kept for callers that look at them
     @property
@@ -447,6 +459,8 @@ class SmootherPipeline:
         ``final``: nothing follows this batch, so its smoother gets an unrestricted stream (the whole chip) instead of the
         smoother partition."""
         torch = self.torch
+        if self.closed:
+            raise RuntimeError("SmootherPipeline is closed")
         k = self._count
         self._count += 1
         fwd_stream = self.fwd_streams[k % len(self.fwd_streams)]
@@ -486,6 +500,8 @@ class SmootherPipeline:
                 after_smoother(bwd_stream)
         done = torch.cuda.Event()
         done.record(bwd_stream)
+        if getattr(db, "_pipeline_done", None) is None:
+            self._batches.append(weakref.ref(db))
         db._pipeline_done = done
         return done
 
@@ -495,11 +511,53 @@ class SmootherPipeline:
         if self._tail_stream is not None:
             self._tail_stream.synchronize()
 
+    @property
+    def closed(self) -> bool:
+        return not self._raw and not self.fwd_streams and not self.bwd_streams
+
     def close(self):
-        for h in self._raw:
-            if h is not None and h.value:
-                self.lib.ste_stream_destroy(h)
-        self._raw = []
+        """Drain and destroy the CU-masked streams.  Idempotent; the pipeline cannot be used afterwards."""
+        try:
+            if self.fwd_streams or self.bwd_streams or self._tail_stream is not None:
+                self.synchronize()
+        finally:
+            # the events recorded on these streams and the ExternalStream wrappers go first, then the streams themselves
+            for ref in self._batches:
+                db = ref()
+                if db is not None and getattr(db, "_pipeline_done", None) is not None:
+                    db._pipeline_done = None
+            self._batches = []
+            self.fwd_streams, self.bwd_streams, self._tail_stream = [], [], None
+            raw, self._raw = self._raw, []
+            for h in raw:
+                if h is not None and h.value:
+                    self.lib.ste_stream_destroy(h)
+            _live_pipelines.discard(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: nothing left to report to
+            pass
+
+
+_live_pipelines = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_pipelines():
+    for pipe in list(_live_pipelines):
+        try:
+            pipe.close()
+        except Exception:
+            pass
 
 
 def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: str = "wgs84", device="cuda:0"):

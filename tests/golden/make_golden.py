@@ -21,7 +21,9 @@ Noise handling: the reference draws from the global unseeded ``np.random.normal`
 ``zero`` cases patch it to return zeros; ``replay`` cases patch it to draw from a seeded ``RandomState`` and record
 every draw in call order, then re-index the draws per step (the layout the oracle and the HIP kernels consume).
 """
+import contextlib
 import copy
+import io
 import os
 import sys
 import types
@@ -365,6 +367,73 @@ def csv_fixture():
     pd.concat([sub, hdr], ignore_index=True).to_csv(os.path.join(HERE, "ship_01203823.csv"), index=False)
 
 
+class _RobustUKF(UnscentedKalmanFilter):
+    """The reference filter with its commented-out robustification call site (unscented.py:228) enabled the way the
+    method's signature says it is meant to be used: ``check_robustness`` (unscented.py:353-387) returns the rescaled
+    measurement covariance and the update that follows runs with it.  Everything executed is the reference's code; this
+    harness only routes the returned R into that one update."""
+
+    def update(self, z):
+        R0 = self.R
+        with contextlib.redirect_stdout(io.StringIO()):  # check_robustness prints every iteration
+            self.R = self.check_robustness(np.asarray(z, dtype=np.float64).reshape(-1, 1), self.P, self.R)
+        try:
+            super().update(z)
+        finally:
+            self.R = R0
+
+
+def robust_cases():
+    """Mahalanobis robustification, noise draws zeroed.
+
+    ``cr_*``: direct calls of the reference's ``check_robustness`` on (x, P, z, R) triples whose outlier size spans no
+    rescaling, one rescaling and several; the returned R and the number of loop iterations are recorded.
+    ``run*_*``: whole tracks through ``_RobustUKF`` (run + run_rts_smoother) with gross outliers injected into some
+    observations, 1 and 2 sub-steps."""
+    rng = np.random.default_rng(2024)
+    H, Q, R, P0 = synthetic.example_matrices()
+    out = dict(H=H, Q=Q, R=R, P0=P0)
+    xs, Ps, zs, Rs, Ro, its = [], [], [], [], [], []
+    scales = [0.1, 0.5, 2.0, 4.0, 6.0, 9.0, 15.0, 30.0, 60.0, 120.0, 3.0, 8.0]
+    for i, sc in enumerate(scales):
+        A = rng.normal(size=(4, 4)) * 0.2
+        P = A @ A.T + np.diag([0.02, 0.02, 0.05, 0.05])
+        x = np.array([rng.uniform(-60, 60), rng.uniform(-60, 60), rng.uniform(5, 40), rng.uniform(0, 360)])
+        z = x + rng.normal(0, 1.0, 4) * sc
+        Rin = R if i < 10 else np.diag([0.25, 0.5, 0.1, 0.1]) + 0.01  # two cases with a dense R
+        Hin = H if i < 10 else np.eye(4)
+        u = UnscentedKalmanFilter(H=Hin, Q=Q, R=Rin, P=P, x0=x)
+        buf = io.StringIO()
+        with NoisePatch("zero"), contextlib.redirect_stdout(buf):
+            Rout = u.check_robustness(z.reshape(-1, 1), P, Rin)
+        xs.append(x); Ps.append(P); zs.append(z); Rs.append(Rin); Ro.append(np.asarray(Rout)); its.append(len(buf.getvalue().splitlines()) - 1)
+    print("robust check_robustness iterations:", its)
+    out.update(cr_x=np.array(xs), cr_P=np.array(Ps), cr_z=np.array(zs), cr_R=np.array(Rs), cr_Rout=np.array(Ro),
+               cr_iters=np.array(its), cr_dense_from=np.int64(10))
+    for ci, (nobs, sub, seed, bumps) in enumerate([(12, 1, 501, {4: (9.0, -6.0)}), (20, 2, 502, {3: (-14.0, 5.0), 11: (25.0, 0.0)}),
+                                                   (16, 2, 503, {0: (7.0, 7.0), 15: (-8.0, 3.0)})]):
+        sb = synthetic.make_batch(1, nobs=nobs, gap_h=1.0, seed0=seed)
+        for col, (dlon, dlat) in bumps.items():
+            sb.z[0, 0, col] += dlon
+            sb.z[0, 1, col] += dlat
+        st = ship_track_from_arrays(sb, 0)
+        x0 = st.z[:, 0].reshape(-1, 1).copy()
+        ukf = _RobustUKF(H=H, Q=Q, R=R, P=P0, x0=x0, non_linear_process=geodetic_dynamics)
+        dt = generate_dts(st.dts, sub)
+        with NoisePatch("zero"):
+            means, covs = ukf.run(nsteps=len(dt), dt=dt, ship_track=st)
+            sm, sc_ = ukf.run_rts_smoother(ship_track=copy.deepcopy(st))
+        assert np.array_equal(ukf.R, R)
+        plain = run_reference(ship_track_from_arrays(sb, 0), H, Q, R, P0, sub, "zero")
+        print(f"robust run{ci}: N={len(dt)} max |robust - plain| lon = {np.abs(means[:, 0] - plain['means'][:, 0]).max():.3f}")
+        out.update({f"run{ci}_z": sb.z[0], f"run{ci}_dts": sb.dts[0], f"run{ci}_sog_rate": sb.sog_rate[0],
+                    f"run{ci}_cog_rate": sb.cog_rate[0], f"run{ci}_substeps": np.int64(sub), f"run{ci}_dt": dt,
+                    f"run{ci}_means": means, f"run{ci}_covs": covs, f"run{ci}_means_smoothed": sm,
+                    f"run{ci}_covs_smoothed": sc_, f"run{ci}_plain_means": plain["means"]})
+    out["nruns"] = np.int64(3)
+    return out
+
+
 def kats():
     """Per-function known answers."""
     rng = np.random.default_rng(7)
@@ -435,10 +504,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "gp.npz"), **gp_cases())
     np.savez_compressed(os.path.join(HERE, "modern_ships.npz"), **modern_cases())
     np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
+    np.savez_compressed(os.path.join(HERE, "robust.npz"), **robust_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py robust prep ...
+        for name in sys.argv[1:]:
+            fn = {"robust": robust_cases, "prep": prep_cases, "examples": example_cases}[name]
+            np.savez_compressed(os.path.join(HERE, {"robust": "robust.npz", "prep": "track_prep.npz",
+                                                    "examples": "batch_examples.npz"}[name]), **fn())
+    else:
+        main()
