@@ -3,25 +3,32 @@
 bench.py — UKF + URTSS track-steps/s on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (forward UKF + unscented RTS smoother) over one batch of synthetic tracks that
-is already resident in HBM.  Workload at N=1: BASELINE.json configs[1] — 10 000 synthetic dim-4 geodetic tracks x 500
-steps, fp64 (126 observations at 1 h gaps, 4 sub-steps).  With N>1 (launched by torch.distributed.run,
-one rank per GPU over RCCL) every rank filters its own 10 000-track shard (weak scaling; tracks are independent) and
-the step ends with the one exchange the path has: an all-gather of the smoothed lon/lat (BASELINE.json configs[2]).
+is already resident in HBM.
+
+Workload
+  N = 1   BASELINE.json configs[1]: 10 000 synthetic dim-4 geodetic tracks x 500 steps, fp64 (126 observations at 1 h
+          gaps, 4 sub-steps).
+  N > 1   BASELINE.json configs[2]: ``--total-tracks`` (default 12 500 x N, i.e. 100 000 at N = 8) cut into contiguous
+          track shards, one rank per GPU (launched by torch.distributed.run over RCCL); tracks are independent, so
+          nothing is exchanged while filtering, and every step ends with the one exchange the path has: an all-gather
+          of the smoothed lon/lat.  Per-GPU work is fixed as N grows ("weak").
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel, algorithmic HBM bytes / HIP-event duration vs 8 TB/s (512 B per
-                track-step for the pair of kernels = 192 B forward + 320 B backward)
+  roofline      dominant kernel (forward filter): algorithmic HBM bytes per launch / its mean HIP-event duration vs
+                8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary under profiles/ (same
+                kernel generation, same command); `fp64_valu` = executed fp64 VALU work from the same summary, beside the
+                nominal SURVEY.md estimate (labelled)
   cpu_baseline  the NumPy oracle ("port" of the reference arithmetic) timed on this box's host cores on a bounded sample
                 (one process, and one forked worker per core of the box's CPU share)
-  serial        the same work without overlapping consecutive steps (see --no-pipeline), for the record
+  serial        one batch at a time, forward then smoother on one unrestricted stream -- the latency figure
 
-Steps are pipelined by default: every step runs the complete forward pass and smoother of one 10 000-track batch, but up
-to four steps are in flight -- two forward passes (625 long-running waves each, two waves per SIMD) on 160 CUs and the two
-smoothers before them (latency-bound) on the other 96, on CU-masked streams, with five sets of history buffers in rotation
-(track_estimators.batch.SmootherPipeline).
+Steps are pipelined by default (track_estimators.batch.SmootherPipeline): every step runs the complete forward pass
+and smoother of one batch, but several steps are in flight -- forward passes on one CU partition, the smoothers of the
+steps before them on the rest, on CU-masked streams, with one set of history buffers per step in flight plus one.
 """
 import argparse
 import contextlib
+import csv
 import json
 import os
 import sys
@@ -35,18 +42,29 @@ for p in (ROOT, PKG_ROOT):
 
 import numpy as np  # noqa: E402
 
-TRACKS_PER_GPU = 10_000
+TRACKS_CONFIG1 = 10_000  # BASELINE.json configs[1]
+TRACKS_PER_GPU_CONFIG2 = 12_500  # BASELINE.json configs[2]: 100 000 tracks over 8 GPUs
 NOBS = 126
 SUBSTEPS = 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6
 BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mean/cov written
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
-# Measured HBM bytes per track-step (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic_v6_quad.csv).
-# Above the algorithmic figure by the rts_work rows the forward pass hands to the smoother.
-TRAFFIC_FWD = 441
-TRAFFIC_BWD = 337 + 560  # urtss_gain_kernel + urtss_combine_l1
-FLOPS_PER_TRACK_STEP = 2.0e4  # SURVEY.md §8d estimate (fp64 flop-equivalents, forward + backward)
+FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
+# rocprofv3 PMC summary of this command for the current kernel generation (see profiles/README.md for the passes)
+COUNTERS_CSV = os.path.join(ROOT, "profiles", "r02_counters_per_track_step.csv")
+
+
+def load_counters():
+    """kernel-name prefix -> dict(hbm_read, hbm_write, fp64_flops) per track-step, from the committed PMC summary."""
+    out = {}
+    try:
+        with open(COUNTERS_CSV) as f:
+            for row in csv.DictReader(ln for ln in f if not ln.startswith("#")):
+                out[row["kernel"]] = {k: float(v) for k, v in row.items() if k != "kernel" and v not in ("", None)}
+    except OSError:
+        pass
+    return out
 
 
 def cpu_baseline(ntracks: int, seed0: int = 0):
@@ -111,19 +129,27 @@ def main():
 def _main(stack):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--tracks", type=int, default=TRACKS_PER_GPU, help="tracks per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--total-tracks", type=int, default=None,
+                    help="tracks of the whole job, cut into one contiguous shard per GPU (default: 10 000 at --gpus 1 = "
+                         "BASELINE configs[1]; 12 500 x N otherwise = configs[2]'s shard size, 100 000 at --gpus 8)")
+    ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (overrides --total-tracks; tests)")
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per track (0 = library default)")
+    ap.add_argument("--lanes", type=int, default=0, help="forward-kernel lanes per track (0 = by batch size, 1, 4)")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run forward and smoother of every step back to back on one stream instead of overlapping the "
-                         "smoother of step i with the forward pass of step i+1 on disjoint CU partitions")
+                         "smoothers of earlier steps with the forward passes of later ones on disjoint CU partitions")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gather even with one rank (rehearsal of the N>1 path)")
     ap.add_argument("--cpu-pool-tracks", type=int, default=768,
                     help="tracks per worker in the all-cores CPU-baseline leg (0 = skip)")
+    # experiments (defaults are the measured best)
+    ap.add_argument("--forward-cus", type=int, default=None)
+    ap.add_argument("--forward-streams", type=int, default=None)
+    ap.add_argument("--smoother-streams", type=int, default=None)
+    ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,35 +184,40 @@ def _main(stack):
                                     device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        stack.callback(dist.destroy_process_group)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    lib = binding.require_gpu()
-    if args.lanes:
-        lib.ste_set_lanes_per_track(args.lanes)
+    binding.require_gpu()
 
-    # --- synthetic shard of this rank, resident in HBM before the timed region ---------------------------------
+    # --- this rank's shard of the synthetic job, resident in HBM before the timed region ------------------------
+    if args.tracks is not None:
+        total = args.tracks * world
+    elif args.total_tracks is not None:
+        total = args.total_tracks
+    else:
+        total = TRACKS_CONFIG1 if world == 1 else TRACKS_PER_GPU_CONFIG2 * world
+    lo, hi = distributed.shard_bounds(total, rank, world)
+    B = hi - lo
+    bmax = -(-total // world)  # largest shard: what the gathered tensor is padded to
     H, Q, R, P0 = synthetic.example_matrices()
-    B = args.tracks
-    sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=rank * B)
+    sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=lo)  # seed = global track index
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
-    db = batch.DeviceBatch(hb, device=dev)
-    # Pipelined mode (default): five sets of histories in rotation; two forward passes at a time share the first 160 CUs
-    # (two waves per SIMD) while the smoothers of the two steps before them share the other 96 (batch.SmootherPipeline).
-    # Every step still does the whole forward + smoother of one batch; nothing is skipped, the steps overlap.
+    hb.lanes = args.lanes
+    db = batch.DeviceBatch(hb, device=dev, tuning=args.tuning)
     pipe = None
     if not args.no_pipeline:
         try:
-            # lane-per-track recurrence on the smoother partition: 1.95 instead of 2.39 ms there, which keeps the smoother
-            # off the critical path now that the forward pass takes 2.38 ms (results differ from the quad recurrence
-            # by rounding, ~1e-13; the oracle cross-check below covers them)
-            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=B, smoother_lane_per_track=True))
+            kw = {k: v for k, v in (("forward_cus", args.forward_cus), ("forward_streams", args.forward_streams),
+                                    ("smoother_streams", args.smoother_streams)) if v is not None}
+            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
-    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev) for _ in range(pipe.buffers_needed - 1)]
+    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev, tuning=args.tuning)
+                                           for _ in range(pipe.buffers_needed - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
-        gathered = distributed.OverlappedGather(hb.Nmax + 1, B, dev)
+        gathered = distributed.OverlappedGather(hb.Nmax + 1, bmax, dev)
 
     stream = torch.cuda.current_stream(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
@@ -219,17 +250,20 @@ def _main(stack):
             gathered.finish()
         torch.cuda.synchronize(dev)
 
-    # back-to-back figure for the record (not the timed region): forward + smoother of one batch on one stream
-    serial_ms = None
+    # one batch at a time (not the timed region): forward + smoother of one batch on one unrestricted stream
+    serial_ms = serial_kernels = None
     if pipe is not None and rank == 0:
         saved, gathered = gathered, None
         serial_step(db)
         torch.cuda.synchronize(dev)
+        sev = [[ev(), ev(), ev(), ev()] for _ in range(3)]
         ts = time.perf_counter()
-        for _ in range(3):
-            serial_step(db)
+        for i in range(3):
+            serial_step(db, sev[i])
         torch.cuda.synchronize(dev)
         serial_ms = (time.perf_counter() - ts) / 3 * 1e3
+        serial_kernels = {"ukf_forward": float(np.mean([e[0].elapsed_time(e[1]) for e in sev])),
+                          "urtss_backward": float(np.mean([e[2].elapsed_time(e[3]) for e in sev]))}
         gathered = saved
 
     for k in range(args.warmup):
@@ -257,19 +291,23 @@ def _main(stack):
     status = db.status_host()
     for d in dbs[1:]:
         status = status | d.status_host()
-    track_steps_rank = hb.track_steps
-    total_units = track_steps_rank * world * args.steps
+    steps_per_track = int(hb.Nmax)
+    total_units = total * steps_per_track * args.steps  # every rank's shard, every timed step
     value = total_units / elapsed
 
     if rank == 0:
-        dom, dom_ms, dom_bytes, dom_traffic = ("urtss_backward", bwd_ms, BYTES_BWD, TRAFFIC_BWD) if bwd_ms >= fwd_ms else (
-            "ukf_forward", fwd_ms, BYTES_FWD, TRAFFIC_FWD)
-        achieved = dom_bytes * track_steps_rank / (dom_ms * 1e-3) / 1e9
-        # whole-job rates of this rank over the timed region (the two kernels overlap in pipelined mode, so their event
-        # durations no longer add up to the step)
-        per_s = track_steps_rank * args.steps / elapsed
-        pair_gbs = (BYTES_FWD + BYTES_BWD) * per_s / 1e9
-        valu_tf = FLOPS_PER_TRACK_STEP * per_s / 1e12
+        track_steps_rank = hb.track_steps
+        counters = load_counters()
+        cf = counters.get("ukf_forward", {})
+        cb = counters.get("urtss_backward", {})
+        # dominant kernel: the forward filter (it holds its partition for the whole step; the smoother hides behind it)
+        achieved = BYTES_FWD * track_steps_rank / (fwd_ms * 1e-3) / 1e9
+        per_s = track_steps_rank * args.steps / elapsed  # this rank's rate over the timed region
+        traffic_fwd = (cf["hbm_read"] + cf["hbm_write"]) * track_steps_rank if "hbm_read" in cf else None
+        traffic_all = None
+        if "hbm_read" in cf and "hbm_read" in cb:
+            traffic_all = cf["hbm_read"] + cf["hbm_write"] + cb["hbm_read"] + cb["hbm_write"]
+        flops_exec = (cf.get("fp64_flops", 0.0) + cb.get("fp64_flops", 0.0)) or None
         out = {
             "metric": "UKF+URTSS track-steps/sec (dim=4, 500-step tracks)",
             "value": value,
@@ -284,40 +322,62 @@ def _main(stack):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{B} synthetic dim-4 geodetic tracks x {hb.Nmax} steps per GPU, UKF+URTSS, fp64 "
-                            "(BASELINE.json configs[1]); zero injected noise; inputs resident in HBM",
-                "tracks_per_gpu": B, "steps_per_track": int(hb.Nmax), "observations": NOBS, "substeps": SUBSTEPS,
+                "workload": (f"{total} synthetic dim-4 geodetic tracks x {steps_per_track} steps, UKF+URTSS, fp64 "
+                             + ("(BASELINE.json configs[1])" if world == 1 and total == TRACKS_CONFIG1 else
+                                f"({'BASELINE.json configs[2]' if total == 100_000 and world == 8 else 'configs[2] shard size'}: "
+                                f"{bmax} tracks per GPU on {world} GPU(s))")
+                             + "; zero injected noise; inputs resident in HBM"),
+                "total_tracks": total, "tracks_per_gpu": bmax, "steps_per_track": steps_per_track, "observations": NOBS,
+                "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (", RCCL all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
-                             f"{len(pipe.fwd_streams)} forward passes in flight on {pipe.forward_cus} CUs (two waves per "
-                             f"SIMD) beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked "
-                             f"streams, {len(dbs)} sets of histories in rotation, lane-per-track recurrence on the smoother "
-                             "partition)"),
-                "lanes_per_track": int(lib.ste_set_lanes_per_track(args.lanes)),
+                             f"{len(pipe.fwd_streams)} forward passes in flight on {pipe.forward_cus} CUs beside "
+                             f"{len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, "
+                             f"{len(dbs)} sets of histories in rotation)"),
+                "lanes_per_track": args.lanes, "tuning": args.tuning,
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},
             "serial": None if serial_ms is None else {
                 "ms_per_step": serial_ms, "value": track_steps_rank / (serial_ms * 1e-3), "unit": "track-steps/s",
-                "note": "one batch, forward then smoother on one unrestricted stream (per GPU, no overlap between steps)"},
+                "kernels_ms": serial_kernels,
+                "note": "one batch at a time, forward then smoother on one unrestricted stream (per GPU, no overlap "
+                        "between steps): the latency figure"},
             "status_flagged_tracks": int((status != 0).sum()),
             "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "ukf_forward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": dom_traffic * track_steps_rank if db.rts_work is not None else None,
+                "traffic": traffic_fwd,
                 "traffic_unit": "bytes per launch",
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v6_quad.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
-                                  "passes of this command; FETCH_SIZE doubled per the gfx950 calibration in profiles/README.md)",
-                "algorithmic_bytes_per_track_step": dom_bytes,
-                "pair_achieved": pair_gbs,
+                "traffic_source": (os.path.relpath(COUNTERS_CSV, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                   "separate passes of this command; FETCH_SIZE doubled per the gfx950 calibration in "
+                                   "profiles/README.md)") if traffic_fwd is not None else None,
+                "algorithmic_bytes_per_track_step": BYTES_FWD,
+                "launch_ms": fwd_ms,
+                "pair": {"algorithmic_bytes_per_track_step": BYTES_FWD + BYTES_BWD,
+                         "achieved": (BYTES_FWD + BYTES_BWD) * per_s / 1e9,
+                         "traffic_bytes_per_track_step": traffic_all,
+                         "traffic_rate": None if traffic_all is None else traffic_all * per_s / 1e9, "unit": "GB/s",
+                         "note": "forward + smoother over the timed region (they overlap in pipelined mode)"},
                 "note": "path is fp64-VALU/latency bound, not HBM bound (SURVEY.md headline 6)",
-                "fp64_valu": {"achieved": valu_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tf / FP64_VALU_PEAK_TFLOPS, "flops_per_track_step": FLOPS_PER_TRACK_STEP},
+                "fp64_valu": {
+                    "executed": None if flops_exec is None else {
+                        "flops_per_track_step": flops_exec, "achieved": flops_exec * per_s / 1e12,
+                        "frac": flops_exec * per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                        "source": os.path.relpath(COUNTERS_CSV, ROOT) + " (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
+                                  "lanes, FMA counted as 2 flops)"},
+                    "nominal": {"flops_per_track_step": FLOPS_NOMINAL, "achieved": FLOPS_NOMINAL * per_s / 1e12,
+                                "frac": FLOPS_NOMINAL * per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                "note": "SURVEY.md §8d estimate of the reference algorithm's flops, NOT what these "
+                                        "kernels execute: an estimate of useful work delivered, not a utilisation"},
+                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s"},
             },
         }
         if world == 1:
             # PCIe-inclusive rate of the host-buffer boundary (batch.run_batch: upload inputs, filter + smooth, download
             # the four history tensors).  Reported for DESIGN.md; it is never `value`.
+            del dbs[1:]
             torch.cuda.synchronize(dev)
+            batch.run_batch(hb, device=dev, smooth=True)  # first call pins its staging buffers
             t1 = time.perf_counter()
             res = batch.run_batch(hb, device=dev, smooth=True)
             t_host = time.perf_counter() - t1
@@ -346,7 +406,6 @@ def _main(stack):
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -21,7 +21,8 @@
  *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - every array pointer is a DEVICE pointer unless marked HOST; the caller owns every buffer, the library never
  *     allocates outputs or frees inputs.
- *   - calls are asynchronous on `stream`; no global state except a thread-local error string.
+ *   - calls are asynchronous on `stream`; no global state except a thread-local error string (launch shape and lane
+ *     mapping are per call: flags / tuning of the batch struct).
  *   - return 0 on success, a negative STE_E* code on argument / launch errors (message via ste_last_error()).
  *   - per-track numerical trouble never aborts a batch: it is reported in status[] (mirrors the batch example's
  *     try/except/continue, example_ukf_rts_smoother_batch.py:73-90).
@@ -42,7 +43,8 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 100 /* 0.1.0 */
+#define STE_VERSION 200 /* 0.2.0: flags LANES_1/LANES_4 and field `tuning` replace ste_set_lanes_per_track and
+                           STE_FLAG_SMOOTHER_LANE_PER_TRACK; STE_STATUS_BAD_INDEX; repeatable backward pass */
 
 /* error codes */
 #define STE_OK 0
@@ -53,17 +55,21 @@ extern "C" {
 /* ste_ukf_batch_f64.flags */
 #define STE_FLAG_SHARED_P0 0x1u        /* P0 is one 4x4 matrix [16] shared by all tracks (else [16][B]) */
 #define STE_FLAG_NO_INITIAL_UPDATE 0x2u /* skip the update with z[:,0] that run() performs before the first predict */
-#define STE_FLAG_SMOOTHER_LANE_PER_TRACK 0x8u /* run the smoother's recurrence with one lane per track whatever the batch
-                                                  size: a quarter of the waves, each longer -- the right shape when the
-                                                  smoother shares the GPU with another kernel (batch.SmootherPipeline) */
+#define STE_FLAG_LANES_1 0x10u /* forward pass with one lane per track for this call (default: chosen by batch size) */
+#define STE_FLAG_LANES_4 0x20u /* forward pass with one DPP quad (4 lanes) per track for this call */
 #define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
                                 the reference ships with its call site commented out, :228) */
+
+#define STE_RTS_WORK_ROWS 22 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work */
 
 /* status[] bits (per track) */
 #define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
 #define STE_STATUS_CLAMPED 0x2    /* sigma fan: negative eigenvalue clamped to 0 (sqrtm went complex in the reference) */
 #define STE_STATUS_NOCONV 0x4     /* Jacobi eigen-solve hit its sweep cap */
 #define STE_STATUS_ROBUST_CAP 0x8 /* robust update: criterion still above chi_alpha after robust_max_iter rescalings */
+#define STE_STATUS_HOST_INDEX 0x10 /* set by host-side packers, never by the library: the reference would raise IndexError
+                                      for this track (update index past its last observation, kalman_filter.py:105) */
+#define STE_STATUS_BAD_INDEX 0x20 /* upd_idx[k] >= Tmax at some step: that update was skipped (precondition below) */
 
 /*
  * One batch of B independent tracks, padded to Nmax filter steps and Tmax observations.
@@ -75,7 +81,8 @@ typedef struct ste_ukf_batch_f64 {
     int32_t Tmax;  /* padded number of observations (columns of ShipTrack.z) */
     int32_t n;     /* state dimension, must be 4 */
     uint32_t flags;
-    int32_t reserved;
+    int32_t tuning; /* 0 = defaults.  Experiments / tests: bits 0-7 = gain (producer) waves per smoother workgroup (1..4),
+                       bit 8 = every smoother gain by the eigenvalue route (default: only near-singular P_b) */
 
     /* sigma-fan constants, computed by the host exactly as unscented.py:95,125,132 does (HOST values) */
     double fan_scale; /* n / (1 - W0) */
@@ -98,7 +105,8 @@ typedef struct ste_ukf_batch_f64 {
     const double* cog_rate;     /* [Nmax][B]                                   (kalman_filter.py:94) */
     const double* sog_rate_rts; /* [Nmax][B]  rate used by the smoother at step k (unscented.py:287-292,310); NULL = sog_rate */
     const double* cog_rate_rts; /* [Nmax][B]  NULL = cog_rate */
-    const int32_t* upd_idx;     /* [Nmax][B]  observation column consumed after step k, -1 = no update (kalman_filter.py:101-108) */
+    const int32_t* upd_idx;     /* [Nmax][B]  observation column consumed after step k, -1 = no update (kalman_filter.py:101-108);
+                                   must be < Tmax: a larger value skips that update and sets STE_STATUS_BAD_INDEX */
     const double* z;            /* [Tmax][4][B] measurement matrix columns (ship_track.py:324-336) */
 
     /* recorded noise draws, already scaled; NULL = zero noise (unscented.py:198,232,320) */
@@ -114,12 +122,16 @@ typedef struct ste_ukf_batch_f64 {
     int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
 
     /*
-     * Optional workspace [Nmax][30][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts == cog_rate_rts ==
-     * NULL, ste_ukf_forward_f64 also evaluates the smoother's per-step back-prediction, P_b and gain K (which depend
-     * only on the filtered state of step k, unscented.py:297-333) while it has the sigma points in registers, stores them
-     * here, and ste_urtss_backward_f64 on the same batch runs only the sequential recurrence (unscented.py:337-349).
-     * Results are those of the stand-alone smoother to rounding.  NULL = the smoother recomputes everything from
-     * fwd_mean / fwd_cov (required when the forward history was not produced by ste_ukf_forward_f64 on this batch).
+     * Optional workspace [Nmax][22][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts == cog_rate_rts ==
+     * NULL, ste_ukf_forward_f64 also evaluates the smoother's per-step back-prediction x_b, P_b and cross-covariance D
+     * (which depend only on the filtered state of step k, unscented.py:297-330) while it has the sigma points in
+     * registers and stores them here (row k: x_b 4 | P_b upper triangle 10 | columns 0-1 of D 8; columns 2-3 of D equal
+     * columns 2-3 of the filtered covariance because speed and heading pass through the process model with unit slope).
+     * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) on the fly and runs the
+     * recurrence (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Tracks
+     * whose forward status carries CLAMPED or NOCONV (the identity for D's last columns needs an exact square root) are
+     * smoothed by the stand-alone kernel in the same call.  Results are those of the stand-alone smoother to rounding.  NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history
+     * was not produced by ste_ukf_forward_f64 on this batch).
      */
     double* rts_work;
 
@@ -295,15 +307,6 @@ int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream);
  * ------------------------------------------------------------------------------------------------------------- */
 int ste_stream_create_cu_range(int32_t first_cu, int32_t num_cus, void** stream);
 int ste_stream_destroy(void* stream);
-
-/*
- * Launch configuration knob for experiments and tests: which lane mapping the forward/backward kernels use.
- *   0 = automatic (forward pass: a quad per track up to 32 768 tracks per launch; smoother recurrence: up to 16 384;
- *       a lane per track above),
- *   1 = one lane per track, 4 = one DPP quad (4 lanes) per track.
- * Returns the previous value.  Process-global; not part of the reference-facing surface.
- */
-int ste_set_lanes_per_track(int lanes);
 
 #ifdef __cplusplus
 }

@@ -4,8 +4,9 @@
 // Kernels:
 //   ukf_forward_q4 / ukf_forward_l1      forward filter, one DPP quad or one lane per track (chosen by batch size);
 //                                        with rts_work they also emit the smoother's x_b, P_b and cross-covariance D
-//   urtss_gain_kernel                    K = D pinv(P_b) for every (track, step) at once -- fills the chip
-//   urtss_combine_q4 / urtss_combine_l1  the sequential smoother recurrence, HBM-bound, prefetch ring
+//   urtss_smooth_wg                      smoother from those rows: per 64 tracks, producer waves turn D into the gain
+//                                        K = D pinv(P_b) one block of steps ahead and hand it through LDS to the wave
+//                                        that runs the sequential recurrence
 //   urtss_backward_l1                    stand-alone smoother that recomputes everything (rts_work == NULL)
 //   predict / update / robust_terms / geodetic / sigma_points kernels   single-step API parity
 // All per-step inputs/outputs are SoA with the track index fastest, so a wave's accesses are contiguous runs.
@@ -29,6 +30,7 @@ namespace ste {
 struct KParams {
     int B, Nmax, Tmax;
     unsigned flags;
+    int tuning;
     Mats m;
     const int32_t* nsteps;
     const double* x0;
@@ -53,8 +55,13 @@ struct KParams {
 
 constexpr int kColdEvery = 64;  // power of two
 
-// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | D, then K in place, row-major (16)
-constexpr int kWorkXb = 0, kWorkPb = 4, kWorkK = 14, kWorkElems = 30;
+// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | columns 0-1 of D, row-major (8).
+// Columns 2-3 of the cross-covariance D are not stored: speed and heading go through the process model with unit slope
+// (non_linear_process.py:74-75), so with T = sqrtm(scale P) and the symmetric fan D[:, 2:4] = 2 wi (T T)[:, 2:4] =
+// P_k[:, 2:4] (2 wi scale = 1 for every n and W0, unscented.py:95,132) -- the filtered covariance the smoother reads
+// anyway.  That identity needs T T = scale P, i.e. an unclamped, converged square root: tracks whose forward status
+// carries CLAMPED or NOCONV are smoothed again by the stand-alone kernel (launch_backward).
+constexpr int kWorkXb = 0, kWorkPb = 4, kWorkD = 14, kWorkElems = 22;
 
 __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
     STE_UNROLL
@@ -310,7 +317,7 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
             }
         }
         // The gain K = D pinv(P_b) is NOT on the forward recursion's critical path: P_b and D are stored and a fully
-        // parallel kernel (urtss_gain_kernel, one lane per (track, step)) turns D into K afterwards.
+        // smoother's producer waves (urtss_smooth_wg) turn D into K afterwards.
         double Pb[4][4], D[4][4];
         weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
         STE_UNROLL
@@ -332,7 +339,7 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = D[r][c];
+            for (int c = 0; c < 2; ++c) w[(kWorkD + r * 2 + c) * B] = D[r][c];
         }
     }
     STE_UNROLL
@@ -424,7 +431,7 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
             }
             rst |= robust_terms(H, R, x, P, z, gamma, denom);
         }
-        if (gamma > p.chi_alpha) rst |= 0x8;
+        if (gamma > p.chi_alpha) rst |= STE_STATUS_ROBUST_CAP;
     }
     if (noise) {
         STE_UNROLL
@@ -550,7 +557,8 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
             const int ui = ui_n;
             // observation for this step's update: address known now, used after the predict
             double zk[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ui >= 0) load_vec(p.z, (size_t)ui, B, t, zk);
+            const bool ui_ok = ui < p.Tmax;  // an observation column past the padded batch: flagged, update skipped
+            if (ui >= 0 && ui_ok) load_vec(p.z, (size_t)ui, B, t, zk);
             // inputs of step k+1: in flight during this step's arithmetic
             if (k + 1 < ns) {
                 const size_t o = (size_t)(k + 1) * B + t;
@@ -567,7 +575,8 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
             }
             st |= ukf_predict<kGains, true>(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t, p.noise_rts, work,
                                             fan_basis, pb_basis);
-            if (ui >= 0) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (ui >= 0 && ui_ok) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
             store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
         }
@@ -605,18 +614,25 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
     quad_scatter(s0, sp, sm, xp, p.w0, p.wi, cx, Pn);
     if (work) {
         const int q = cx.q;
-        double xb[4], dlt[4], D[4], bv[4], bx[4];
+        double xb[4], D[2], bv[4], bx[4];
         STE_UNROLL
         for (int c = 0; c < 4; ++c) {
             xb[c] = m[c];
-            dlt[c] = sp[c] - sm[c];
             bv[c] = xp[c] - x[c];
         }
         if (noise_rts) {
             STE_UNROLL
             for (int c = 0; c < 4; ++c) xb[c] += noise_rts[(nrow * 4 + c) * B + t];
         }
-        quad_mm_rows(Tn, dlt, D);
+        STE_UNROLL
+        for (int c = 0; c < 2; ++c) {  // columns 0-1 of D (row q): sum_l T[q][l] (chi'_{l+} - chi'_{l-})[c]
+            const double dlt = sp[c] - sm[c];
+            double acc = Tn[0] * bcast<0>(dlt);
+            acc = fma(Tn[1], bcast<1>(dlt), acc);
+            acc = fma(Tn[2], bcast<2>(dlt), acc);
+            acc = fma(Tn[3], bcast<3>(dlt), acc);
+            D[c] = acc;
+        }
         xorperm(bv, q, bx);
         double Pb[4];
         STE_UNROLL
@@ -637,7 +653,7 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
             if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pb[s];
         }
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) w[(kWorkK + q * 4 + c) * B] = p.wi * D[c];
+        for (int c = 0; c < 2; ++c) w[(kWorkD + q * 2 + c) * B] = p.wi * D[c];
     }
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
@@ -649,6 +665,7 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
 
 // Measurement update for a quad (unscented.py:219-265): every 4x4 product is one row per lane, rows of the other
 // operand arrive by quad broadcasts.
+template <bool kRobust>
 __device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
                                            const double (&zin)[4], const double* noise, size_t nrow, size_t B,
                                            size_t t) {
@@ -669,10 +686,58 @@ __device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, dou
         for (int k = 1; k < 4; ++k) acc = fma(Px[k], cx.HTx[c][k], acc);
         G[c] = acc;
     }
-    quad_mm_rows(cx.Hrow, G, Sn);  // S = H G + R
+    quad_mm_rows(cx.Hrow, G, Sn);  // H G = H P H^T (row q)
+    double Rrow[4];                // row q of the measurement covariance this update runs with
     STE_UNROLL
-    for (int c = 0; c < 4; ++c) Sn[c] += cx.Rrow[c];
-    const int st = quad_sym_pinv(Sn, cx, Sin);
+    for (int c = 0; c < 4; ++c) Rrow[c] = cx.Rrow[c];
+    int rst = 0;
+    if (kRobust) {
+        // Opt-in robustification (check_robustness, unscented.py:353-387) on the un-noised observation with the
+        // reference's y = z - x: while gamma = |y^T S^+ y| exceeds chi_alpha, lambda += (gamma - chi)/(y^T S^+ R S^+ y) and
+        // R <- lambda R (compounding, as written there).  A quad's four lanes see the same gamma; tracks that are done
+        // keep their values while others in the wave iterate.
+        double y0[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) y0[c] = zin[c] - x[c];
+        const double yq = sel4(y0, q);
+        auto terms = [&](double& gamma, double& denom) -> int {
+            double S[4], Si[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) S[c] = Sn[c] + Rrow[c];
+            const int pst = quad_sym_pinv(S, cx, Si);
+            double uq = 0.0;  // (S^+ y)[q]
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) uq = fma(Si[c], y0[c], uq);
+            gamma = fabs(quad_sum(yq * uq));
+            double vq = 0.0;  // (R S^+ y)[q]
+            vq = fma(Rrow[0], bcast<0>(uq), vq);
+            vq = fma(Rrow[1], bcast<1>(uq), vq);
+            vq = fma(Rrow[2], bcast<2>(uq), vq);
+            vq = fma(Rrow[3], bcast<3>(uq), vq);
+            denom = quad_sum(uq * vq);
+            return pst;
+        };
+        double gamma, denom, lambda = 1.0;
+        rst |= terms(gamma, denom);
+        for (int it = 0; it < p.robust_iters; ++it) {
+            const bool active = gamma > p.chi_alpha;
+            if (!__any(active)) break;
+            lambda = active ? lambda + (gamma - p.chi_alpha) / denom : lambda;
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Rrow[c] = active ? Rrow[c] * lambda : Rrow[c];
+            double g2, d2;
+            const int pst = terms(g2, d2);
+            if (active) {
+                rst |= pst;
+                gamma = g2;
+                denom = d2;
+            }
+        }
+        if (gamma > p.chi_alpha) rst |= STE_STATUS_ROBUST_CAP;
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) Sn[c] += Rrow[c];  // S = H P H^T + R
+    const int st = quad_sym_pinv(Sn, cx, Sin) | rst;
     quad_mm_rows(G, Sin, K);  // K = G S^+  (row q)
     double y[4];
     STE_UNROLL
@@ -703,6 +768,7 @@ __device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, dou
         A[c] = ((c == q) ? 1.0 : 0.0) - kh;
         KR[c] = kr;
     }
+    if (kRobust) quad_mm_rows(K, Rrow, KR);  // K R with this update's rescaled R (rows live one per lane)
     xorperm(Px, q, Pnat);
     quad_mm_rows(A, Pnat, AP);
     quad_mm_rows_t(AP, A, P1);
@@ -713,7 +779,7 @@ __device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, dou
     return st;
 }
 
-template <bool kGains>
+template <bool kGains, bool kRobust>
 // __launch_bounds__(64, 2): at most 256 VGPRs, so that two waves fit on a SIMD.  What no longer fits is needed only by the
 // branching fallback of the propagation (its library-call constants go to scratch); the step loop itself has no scratch
 // access.  Alone the kernel is 5 % faster than the 362-VGPR build (no AGPR traffic), and two forward passes on the same
@@ -761,7 +827,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
-        st |= quad_update(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+        st |= quad_update<kRobust>(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
     QuadBasis basis;
     basis.valid = false;
@@ -782,7 +848,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             // Unconditional loads with clamped indices: a load inside an `if` makes hipcc drain the queue with
             // s_waitcnt vmcnt(0) where the branch rejoins, i.e. right after issuing it -- a full HBM round trip per step.
             double zk[4];
-            load_vec(p.z, (size_t)(ui >= 0 ? ui : 0), B, t, zk);
+            const bool ui_ok = ui < p.Tmax;  // an observation column past the padded batch: flagged, update skipped
+            load_vec(p.z, (size_t)((ui >= 0 && ui_ok) ? ui : 0), B, t, zk);
             {
                 const size_t o = (size_t)(k + 1 < ns ? k + 1 : k) * B + t;
                 dt_n = p.dt[o];
@@ -793,7 +860,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t);
-            if (ui >= 0) st |= quad_update(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (ui >= 0 && ui_ok) st |= quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_row((size_t)k + 1);
         }
     }
@@ -809,20 +877,28 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // URTSS backward pass, one lane per track (unscented.py:285-351)
 // ---------------------------------------------------------------------------------------------------------------
+// kFlaggedOnly: redo just the tracks whose forward status says the square root of some step was clamped or did not
+// converge (the compact work rows of the fused path assume T T = scale P, see kWorkD); waves without such a track leave
+// at once, so on clean batches this launch costs a few microseconds.
+template <bool kFlaggedOnly>
 __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= B) return;
-    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    const bool mine = !kFlaggedOnly || (p.status[t] & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
+    if (kFlaggedOnly && !__any(mine)) return;
+    const int ns = mine ? (p.nsteps ? p.nsteps[t] : p.Nmax) : -1;  // -1: this lane only keeps the others company
     const double* srp = p.sog_rate_rts ? p.sog_rate_rts : p.sog_rate;
     const double* crp = p.cog_rate_rts ? p.cog_rate_rts : p.cog_rate;
 
     // row ns: smoothed = filtered
     double xs[4], Ps[4][4];
-    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
-    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
-    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+    load_vec(p.fwd_mean, (size_t)(ns < 0 ? 0 : ns), B, t, xs);
+    load_mat(p.fwd_cov, (size_t)(ns < 0 ? 0 : ns), B, t, Ps);
+    if (mine) {
+        store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+        store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+    }
 
     // filtered row of the first step to process, prefetched
     double xn[4] = {0, 0, 0, 0}, Pn[4][4] = {};
@@ -928,212 +1004,222 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
         }
     }
     if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
-    p.status[t] |= st;
+    if (mine && st) atomicOr(&p.status[t], st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// URTSS backward recurrence from gains precomputed by ukf_forward_l1<true> (unscented.py:337-349), one lane per track.
-// Per step it reads the filtered row (20 doubles) and the gain row (30 doubles) and writes the smoothed row (20): it is
-// HBM-latency/bandwidth bound, so the next step's 50 loads are issued before this step's arithmetic.
+// URTSS backward pass from the rows the forward pass left in rts_work (x_b, P_b, D of every step; unscented.py:297-330):
+// one workgroup per 64 tracks, lane = track in every wave.
+//   waves 1..NP ("producers")  K = D pinv(P_b) (unscented.py:333) for one step each of the next block of NP steps --
+//                              this does not depend on the recurrence, so it runs one block ahead of it;
+//   wave 0 ("consumer")        the sequential recurrence (unscented.py:337-349) over the block the producers finished
+//                              in the previous iteration, reading K and P_b from LDS.
+// K never goes to HBM and D is not overwritten, so the pass can be repeated; per track-step it reads 22 doubles of work
+// row + 18 of history (mean, upper triangle of the covariance, x_b) and writes the 20 of the smoothed row (the seven
+// covariance entries the producers read again are the consumer's own, one block earlier: L2 hits).  One barrier
+// per block of NP steps; two LDS buffers of NP x 26 x 64 doubles.  The consumer keeps the history rows of the next
+// block in flight (ring of NP rows, the slot index is the position in the block, so it is static after unrolling);
+// each producer keeps its next work row in flight.
 // ---------------------------------------------------------------------------------------------------------------
-// K = D pinv(P_b) for every (track, step) at once (unscented.py:333).  Independent work items: the grid covers
-// Nmax*B lanes (track index fastest, so loads and stores stay coalesced) and fills every SIMD, unlike the sequential
-// passes.  Each lane: 26 loads, one 4x4 Jacobi eigen-solve, one 4x4 product, 16 stores.
-__global__ __launch_bounds__(256) void urtss_gain_kernel(const KParams p) {
-    const size_t B = (size_t)p.B;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)p.Nmax * B) return;
-    const size_t k = i / B, t = i - k * B;
-    if (p.nsteps && (int)k >= p.nsteps[t]) return;
-    double* w = p.rts_work + (k * kWorkElems) * B + t;
-    double Pb[4][4], D[4][4], Pbi[4][4], K[4][4];
-    int e = kWorkPb;
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = r; c < 4; ++c) {
-            const double v = w[(e++) * B];
-            Pb[r][c] = v;
-            Pb[c][r] = v;
-        }
-    }
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) D[r][c] = w[(kWorkK + r * 4 + c) * B];
-    }
-    const int st = sym_pinv4(Pb, Pbi);
-    mm(D, Pbi, K);
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) w[(kWorkK + r * 4 + c) * B] = K[r][c];
-    }
-    if (st) atomicOr(&p.status[t], st);
-}
+constexpr int kSmoothLdsRow = 26;  // K (16) | P_b upper triangle (10), each [64 lanes]
 
-struct GainRow {
-    double xk[4], Pk[4][4], xb[4], Pb[4][4], K[4][4];
+struct HistRow {
+    double xk[4], Pk[10], xb[4];
 };
-__device__ __forceinline__ void load_gain_row(const KParams& p, size_t k, size_t B, size_t t, GainRow& g) {
+__device__ __forceinline__ void load_hist_row(const KParams& p, size_t k, size_t B, size_t t, HistRow& g) {
     load_vec(p.fwd_mean, k, B, t, g.xk);
-    load_mat(p.fwd_cov, k, B, t, g.Pk);
+    int e = 0;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) g.Pk[e++] = p.fwd_cov[(k * 16 + r * 4 + c) * B + t];
+    }
     const double* w = p.rts_work + (k * kWorkElems) * B + t;
     STE_UNROLL
     for (int c = 0; c < 4; ++c) g.xb[c] = w[(kWorkXb + c) * B];
-    int e = kWorkPb;
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = r; c < 4; ++c) {
-            const double v = w[(e++) * B];
-            g.Pb[r][c] = v;
-            g.Pb[c][r] = v;
-        }
-    }
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) g.K[r][c] = w[(kWorkK + r * 4 + c) * B];
-    }
 }
 
-__global__ __launch_bounds__(64) void urtss_combine_l1(const KParams p) {
-    const size_t B = (size_t)p.B;
-    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
-    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
-    double xs[4], Ps[4][4];
-    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
-    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
-    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
-    GainRow nxt;
-    if (ns > 0) load_gain_row(p, (size_t)ns - 1, B, t, nxt);
-    for (int k = p.Nmax - 1; k >= 0; --k) {
-        if (!__any(k < ns)) continue;
-        if (k < ns) {
-            const GainRow g = nxt;
-            if (k > 0) load_gain_row(p, (size_t)k - 1, B, t, nxt);
-            double y[4];
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) y[c] = xs[c] - g.xb[c];
-            y[3] = wrap180(y[3]);
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                double acc = g.xk[r];
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) acc = fma(g.K[r][c], y[c], acc);
-                xs[r] = acc;
-            }
-            xs[3] = floored_mod(xs[3], 360.0);
-            double dP[4][4], KdP[4][4], U[4][4];
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) dP[r][c] = Ps[r][c] - g.Pb[r][c];
-            }
-            mm(g.K, dP, KdP);
-            mmt_sym(KdP, g.K, U);
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) Ps[r][c] = g.Pk[r][c] + U[r][c];
-            }
-            store_vec(p.sm_mean, (size_t)k, B, t, xs);
-            store_mat(p.sm_cov, (size_t)k, B, t, Ps);
-        }
-    }
-    int st = 0;
-    if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
-    p.status[t] |= st;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same recurrence with one DPP quad per track: lane q owns row q of the matrices (natural order) and component q
-// of the mean.  17 loads and ~75 fp64 issue slots per lane and step instead of 50 and ~190, four times as many waves,
-// and a three-deep ring of prefetched rows so that two steps' loads are always in flight behind the one being consumed.
-// ---------------------------------------------------------------------------------------------------------------
-struct GainRowQ {
-    double xk, Pk[4], xb[4], Pb[4], K[4];
+struct WorkRow {
+    double Pb[10], D2[8], Pc[7];  // Pc: filtered covariance entries (0,2) (0,3) (1,2) (1,3) (2,2) (2,3) (3,3) = columns 2-3 of D
 };
-__device__ __forceinline__ void load_gain_row_q(const KParams& p, size_t k, size_t B, size_t t, int q, GainRowQ& g) {
-    g.xk = p.fwd_mean[(k * 4 + q) * B + t];
+__device__ __forceinline__ void load_work_row(const KParams& p, size_t k, size_t B, size_t t, WorkRow& g) {
     const double* w = p.rts_work + (k * kWorkElems) * B + t;
     STE_UNROLL
-    for (int c = 0; c < 4; ++c) {
-        g.Pk[c] = p.fwd_cov[(k * 16 + q * 4 + c) * B + t];
-        g.xb[c] = w[(kWorkXb + c) * B];
-        const int lo = q < c ? q : c, hi = q < c ? c : q;
-        g.Pb[c] = w[(kWorkPb + tri_index(lo, hi)) * B];
-        g.K[c] = w[(kWorkK + q * 4 + c) * B];
-    }
+    for (int e = 0; e < 10; ++e) g.Pb[e] = w[(kWorkPb + e) * B];
+    STE_UNROLL
+    for (int e = 0; e < 8; ++e) g.D2[e] = w[(kWorkD + e) * B];
+    constexpr int idx[7] = {2, 3, 6, 7, 10, 11, 15};
+    STE_UNROLL
+    for (int e = 0; e < 7; ++e) g.Pc[e] = p.fwd_cov[(k * 16 + idx[e]) * B + t];
 }
 
-__device__ __forceinline__ void combine_step_q(const KParams& p, const GainRowQ& g, size_t k, size_t B, size_t t, int q,
-                                               double (&xs)[4], double (&Ps)[4]) {
-    double y[4];
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) y[c] = xs[c] - g.xb[c];
-    y[3] = wrap180(y[3]);
-    double xq = g.xk;
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) xq = fma(g.K[c], y[c], xq);
-    xs[0] = bcast<0>(xq);
-    xs[1] = bcast<1>(xq);
-    xs[2] = bcast<2>(xq);
-    xs[3] = floored_mod(bcast<3>(xq), 360.0);
-    double dP[4], KdP[4], U[4];
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) dP[c] = Ps[c] - g.Pb[c];
-    quad_mm_rows(g.K, dP, KdP);
-    quad_mm_rows_t(KdP, g.K, U);
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) Ps[c] = g.Pk[c] + U[c];
-    p.sm_mean[(k * 4 + q) * B + t] = (q == 3) ? xs[3] : xq;
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) p.sm_cov[(k * 16 + q * 4 + c) * B + t] = Ps[c];
-}
-
-__global__ __launch_bounds__(64) void urtss_combine_q4(const KParams p) {
+template <int NP, bool kEigGains>
+__global__ __launch_bounds__((NP + 1) * 64) void urtss_smooth_wg(const KParams p) {
+    __shared__ double lds[2 * NP * kSmoothLdsRow * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t B = (size_t)p.B;
-    const size_t gl = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const size_t t = gl >> 2;
-    const int q = (int)(gl & 3);
-    if (t >= B) return;
-    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
-    double xs[4], Ps[4];
+    const size_t t_raw = (size_t)blockIdx.x * 64 + lane;
+    const bool valid = t_raw < B;
+    const size_t t = valid ? t_raw : B - 1;  // idle lanes shadow the last track (loads only) and take part in the barriers
+    const int ns = valid ? (p.nsteps ? p.nsteps[t] : p.Nmax) : 0;
+    int nsmax = ns;
     STE_UNROLL
-    for (int c = 0; c < 4; ++c) {
-        xs[c] = p.fwd_mean[((size_t)ns * 4 + c) * B + t];
-        Ps[c] = p.fwd_cov[((size_t)ns * 16 + q * 4 + c) * B + t];
+    for (int off = 32; off >= 1; off >>= 1) nsmax = max(nsmax, __shfl_xor(nsmax, off, 64));
+    const int nblk = (nsmax + NP - 1) / NP;  // the same in every wave of the workgroup: they hold the same 64 tracks
+    const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
+    auto slot = [&](int blk, int i) -> double* { return lds + ((size_t)((blk & 1) * NP + i) * kSmoothLdsRow) * 64 + lane; };
+    int st = 0;
+
+    if (wave == 0) {
+        // ---- consumer: the recurrence ---------------------------------------------------------------------------
+        double xs[4], Ps[4][4];
+        load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+        load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
+        if (valid) {  // row ns: smoothed = filtered
+            store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+            store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+        }
+        HistRow ring[NP];
+        if (nblk > 0) {
+            STE_UNROLL
+            for (int i = 0; i < NP; ++i) load_hist_row(p, (size_t)min((nblk - 1) * NP + i, last_row), B, t, ring[i]);
+        }
+        for (int it = nblk - 1; it >= -1; --it) {
+            const int jb = it + 1;
+            if (jb < nblk) {
+                STE_UNROLL
+                for (int i = NP - 1; i >= 0; --i) {
+                    const int k = jb * NP + i;
+                    if (k < ns) {
+                        const HistRow& g = ring[i];
+                        const double* l = slot(jb, i);
+                        double K[4][4], Pb[4][4];
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            STE_UNROLL
+                            for (int c = 0; c < 4; ++c) K[r][c] = l[(r * 4 + c) * 64];
+                        }
+                        int e = 16;
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            STE_UNROLL
+                            for (int c = r; c < 4; ++c) {
+                                const double v = l[(e++) * 64];
+                                Pb[r][c] = v;
+                                Pb[c][r] = v;
+                            }
+                        }
+                        double y[4];
+                        STE_UNROLL
+                        for (int c = 0; c < 4; ++c) y[c] = xs[c] - g.xb[c];
+                        y[3] = wrap180(y[3]);
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            double acc = g.xk[r];
+                            STE_UNROLL
+                            for (int c = 0; c < 4; ++c) acc = fma(K[r][c], y[c], acc);
+                            xs[r] = acc;
+                        }
+                        xs[3] = floored_mod(xs[3], 360.0);
+                        double dP[4][4], KdP[4][4], U[4][4];
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            STE_UNROLL
+                            for (int c = 0; c < 4; ++c) dP[r][c] = Ps[r][c] - Pb[r][c];
+                        }
+                        mm(K, dP, KdP);
+                        mmt_sym(KdP, K, U);
+                        e = 0;
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            STE_UNROLL
+                            for (int c = r; c < 4; ++c) {
+                                const double v = g.Pk[e++] + U[r][c];
+                                Ps[r][c] = v;
+                                Ps[c][r] = v;
+                            }
+                        }
+                        store_vec(p.sm_mean, (size_t)k, B, t, xs);
+                        store_mat(p.sm_cov, (size_t)k, B, t, Ps);
+                    }
+                    // the row this slot holds in the next block; unconditional (clamped) so that no load sits in a branch
+                    const int kl = k - NP;
+                    load_hist_row(p, (size_t)min(max(kl, 0), last_row), B, t, ring[i]);
+                }
+            }
+            __syncthreads();
+        }
+        if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
+    } else {
+        // ---- producers: gains one block ahead ---------------------------------------------------------------------
+        const int i = wave - 1;
+        WorkRow nxt;
+        if (nblk > 0) load_work_row(p, (size_t)min((nblk - 1) * NP + i, last_row), B, t, nxt);
+        for (int it = nblk - 1; it >= -1; --it) {
+            if (it >= 0) {
+                const int k = it * NP + i;
+                const WorkRow cur = nxt;
+                load_work_row(p, (size_t)min(max(k - NP, 0), last_row), B, t, nxt);
+                const bool active = k < ns;
+                double au[10], D[4][4], K[4][4];
+                STE_UNROLL
+                for (int e = 0; e < 10; ++e) {  // idle lanes: the identity, nothing to solve
+                    const bool diag = (e == 0 || e == 4 || e == 7 || e == 9);
+                    au[e] = active ? cur.Pb[e] : (diag ? 1.0 : 0.0);
+                }
+                {
+                    // D = [stored columns 0-1 | columns 2-3 of the filtered covariance] (see kWorkD)
+                    const double c2[4] = {cur.Pc[0], cur.Pc[2], cur.Pc[4], cur.Pc[5]};
+                    const double c3[4] = {cur.Pc[1], cur.Pc[3], cur.Pc[5], cur.Pc[6]};
+                    STE_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        D[r][0] = active ? cur.D2[r * 2 + 0] : 0.0;
+                        D[r][1] = active ? cur.D2[r * 2 + 1] : 0.0;
+                        D[r][2] = active ? c2[r] : 0.0;
+                        D[r][3] = active ? c3[r] : 0.0;
+                    }
+                }
+                // K = D pinv(P_b) (unscented.py:333): by factorisation where P_b is safely invertible (then pinv is the
+                // inverse), by the eigenvalue route -- with NumPy's rank cutoff -- for the lanes where it is not
+                const bool bad = kEigGains ? true : ldl_right_solve4(au, D, K);
+                if (__any(bad)) {
+                    double Pb[4][4], Pbi[4][4], K2[4][4];
+                    int e = 0;
+                    STE_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        STE_UNROLL
+                        for (int c = r; c < 4; ++c) {
+                            Pb[r][c] = au[e];
+                            Pb[c][r] = au[e];
+                            ++e;
+                        }
+                    }
+                    const int pst = sym_pinv4(Pb, Pbi);
+                    mm(D, Pbi, K2);
+                    if (bad) {
+                        if (active) st |= pst;
+                        STE_UNROLL
+                        for (int r = 0; r < 4; ++r) {
+                            STE_UNROLL
+                            for (int c = 0; c < 4; ++c) K[r][c] = K2[r][c];
+                        }
+                    }
+                }
+                double* l = slot(it, i);
+                STE_UNROLL
+                for (int r = 0; r < 4; ++r) {
+                    STE_UNROLL
+                    for (int c = 0; c < 4; ++c) l[(r * 4 + c) * 64] = K[r][c];
+                }
+                STE_UNROLL
+                for (int q = 0; q < 10; ++q) l[(16 + q) * 64] = cur.Pb[q];
+            }
+            __syncthreads();
+        }
     }
-    p.sm_mean[((size_t)ns * 4 + q) * B + t] = sel4(xs, q);
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) p.sm_cov[((size_t)ns * 16 + q * 4 + c) * B + t] = Ps[c];
-    // ring[kk % 3] holds row kk.  Iteration kk first consumes its slot (lanes with kk < ns), then refills the same slot
-    // with row kk - 3, so a lane's first row (ns - 1) is requested at kk = ns + 2 and two rows stay in flight.
-    GainRowQ ring0, ring1, ring2;
-    auto iteration = [&](int kk, GainRowQ& slot) {
-        if (kk < p.Nmax && kk < ns) combine_step_q(p, slot, (size_t)kk, B, t, q, xs, Ps);
-        const int kl = kk - 3;
-        if (kl >= 0 && kl < ns) load_gain_row_q(p, (size_t)kl, B, t, q, slot);
-    };
-    for (int base = ((p.Nmax + 2) / 3) * 3 + 2; base >= 2; base -= 3) {
-        if (!__any(base - 5 < ns)) continue;  // ragged batch: nobody in this wave is within reach yet
-        iteration(base, ring2);
-        iteration(base - 1, ring1);
-        iteration(base - 2, ring0);
-    }
-    double chk = 0.0;
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) chk += xs[c] * 0.0 + Ps[c] * 0.0;
-    int st = (chk == 0.0) ? 0 : STE_STATUS_NAN;
-    st |= dpp_move_i<0xB1>(st);
-    st |= dpp_move_i<0x4E>(st);
-    if (q == 0 && st) p.status[t] |= st;
+    if (st && valid) atomicOr(&p.status[t], st);
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // single-function kernels (fine-grained API parity: geodetic_dynamics, compute_sigma_points)
@@ -1286,21 +1372,16 @@ __global__ __launch_bounds__(64) void robust_terms_kernel(size_t count, const Ma
 namespace {
 
 thread_local char g_err[512] = "";
-int g_lanes_per_track = 0;  // 0 = automatic
-// Lane mapping of the sequential kernels.  A quad per track shortens the per-wave instruction stream ~1.7x and puts 4x
-// as many waves on the chip, but replicates work across its lanes.  The quad forward kernel fits two waves on a SIMD
-// (<= 256 VGPRs), so it stays a single round up to 32 768 tracks (2 048 waves); the quad recurrence of the smoother
-// (264 VGPRs, one wave per SIMD) only up to 16 384, after which the lane-per-track recurrence takes over.
-// Measured on MI355X, forward + smoother, ms:
-//   tracks                     12 288   16 384   20 480   32 768   40 960
-//   quad forward + quad smoother 3.71     4.23     6.47     7.38    10.41
-//   lane forward + lane smoother 5.65     5.85     6.52     7.29     8.29
-constexpr int kQuadMaxTracks = 32768;          // forward pass
-constexpr int kQuadSmootherMaxTracks = 16384;  // smoother recurrence
-int choose_lanes(int B, bool robust, bool smoother = false) {
-    if (robust) return 1;  // the robust update exists in the lane-per-track kernels only
-    if (g_lanes_per_track == 1 || g_lanes_per_track == 4) return g_lanes_per_track;
-    return B <= (smoother ? kQuadSmootherMaxTracks : kQuadMaxTracks) ? 4 : 1;
+// Lane mapping of the forward kernel.  A quad per track shortens the per-wave instruction stream ~1.7x and puts 4x as
+// many waves on the chip, but replicates work across its lanes.  The quad forward kernel fits two waves on a SIMD
+// (<= 256 VGPRs), so it stays a single round up to 32 768 tracks (2 048 waves), after which one lane per track wins
+// (measured on MI355X).  STE_FLAG_LANES_1 / STE_FLAG_LANES_4 in the batch's flags override the choice for
+// that call.
+constexpr int kQuadMaxTracks = 32768;
+int choose_lanes(int B, unsigned flags) {
+    if (flags & STE_FLAG_LANES_1) return 1;
+    if (flags & STE_FLAG_LANES_4) return 4;
+    return B <= kQuadMaxTracks ? 4 : 1;
 }
 
 int fail(int code, const char* fmt, const char* detail = "") {
@@ -1338,7 +1419,10 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->B = b->B;
     kp->Nmax = b->Nmax;
     kp->Tmax = b->Tmax;
+    if ((b->flags & STE_FLAG_LANES_1) && (b->flags & STE_FLAG_LANES_4))
+        return fail(STE_EINVAL, "STE_FLAG_LANES_1 and STE_FLAG_LANES_4 exclude each other");
     kp->flags = b->flags;
+    kp->tuning = b->tuning;
     kp->m.fan_scale = b->fan_scale;
     kp->m.w0 = b->w0;
     kp->m.wi = b->wi;
@@ -1371,12 +1455,20 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
 }
 
 int launch_forward(const ste::KParams& kp, hipStream_t s) {
-    if (choose_lanes(kp.B, kp.m.robust_iters > 0) == 4) {
+    const bool robust = kp.m.robust_iters > 0;
+    if (choose_lanes(kp.B, kp.flags) == 4) {
         const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
-        if (kp.rts_work)
-            hipLaunchKernelGGL(ste::ukf_forward_q4<true>, dim3(gridq), dim3(64), 0, s, kp);
-        else
-            hipLaunchKernelGGL(ste::ukf_forward_q4<false>, dim3(gridq), dim3(64), 0, s, kp);
+        if (robust) {
+            if (kp.rts_work)
+                hipLaunchKernelGGL((ste::ukf_forward_q4<true, true>), dim3(gridq), dim3(64), 0, s, kp);
+            else
+                hipLaunchKernelGGL((ste::ukf_forward_q4<false, true>), dim3(gridq), dim3(64), 0, s, kp);
+        } else {
+            if (kp.rts_work)
+                hipLaunchKernelGGL((ste::ukf_forward_q4<true, false>), dim3(gridq), dim3(64), 0, s, kp);
+            else
+                hipLaunchKernelGGL((ste::ukf_forward_q4<false, false>), dim3(gridq), dim3(64), 0, s, kp);
+        }
         return check_hip(hipGetLastError(), "ukf_forward_q4 launch");
     }
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
@@ -1387,23 +1479,30 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
     return check_hip(hipGetLastError(), "ukf_forward launch");
 }
 
+// Shape of the smoother workgroup: producer waves per consumer wave (tuning & 0xff) and whether every gain goes the
+// eigenvalue route (tuning & 0x100) instead of only the ones whose P_b is close to singular.
+template <int NP>
+void launch_smooth(const ste::KParams& kp, unsigned grid, hipStream_t s) {
+    if (kp.tuning & 0x100)
+        hipLaunchKernelGGL((ste::urtss_smooth_wg<NP, true>), dim3(grid), dim3((NP + 1) * 64), 0, s, kp);
+    else
+        hipLaunchKernelGGL((ste::urtss_smooth_wg<NP, false>), dim3(grid), dim3((NP + 1) * 64), 0, s, kp);
+}
+
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
     if (kp.rts_work) {
-        const size_t items = (size_t)kp.Nmax * (size_t)kp.B;
-        if (items) {
-            hipLaunchKernelGGL(ste::urtss_gain_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, kp);
-            int rc = check_hip(hipGetLastError(), "urtss_gain launch");
-            if (rc) return rc;
+        switch (kp.tuning & 0xff) {
+            case 1: launch_smooth<1>(kp, grid, s); break;
+            case 2: launch_smooth<2>(kp, grid, s); break;
+            case 4: launch_smooth<4>(kp, grid, s); break;
+            default: launch_smooth<3>(kp, grid, s); break;
         }
-        if (!(kp.flags & STE_FLAG_SMOOTHER_LANE_PER_TRACK) && choose_lanes(kp.B, false, true) == 4) {
-            const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
-            hipLaunchKernelGGL(ste::urtss_combine_q4, dim3(gridq), dim3(64), 0, s, kp);
-        } else {
-            hipLaunchKernelGGL(ste::urtss_combine_l1, dim3(grid), dim3(64), 0, s, kp);
-        }
+        int rc = check_hip(hipGetLastError(), "urtss_smooth_wg launch");
+        if (rc) return rc;
+        hipLaunchKernelGGL(ste::urtss_backward_l1<true>, dim3(grid), dim3(64), 0, s, kp);
     } else
-        hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
+        hipLaunchKernelGGL(ste::urtss_backward_l1<false>, dim3(grid), dim3(64), 0, s, kp);
     return check_hip(hipGetLastError(), "urtss_backward launch");
 }
 
@@ -1419,12 +1518,6 @@ int ste_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
-
-int ste_set_lanes_per_track(int lanes) {
-    const int prev = g_lanes_per_track;
-    if (lanes == 0 || lanes == 1 || lanes == 4) g_lanes_per_track = lanes;
-    return prev;
 }
 
 int ste_stream_create_cu_range(int32_t first_cu, int32_t num_cus, void** stream) {

@@ -590,6 +590,53 @@ __device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4
     return sym_pinv4<false>(S, Si, none);
 }
 
+// 1/d for normal d of either sign: v_rcp_f64 (~2^-24) and two Newton steps (below 2^-80 before the final rounding).
+__device__ __forceinline__ double rcp_refined(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+// K = D A^-1 for a symmetric 4x4 A given by its upper triangle au[10] (row-major: 00 01 02 03 11 12 13 22 23 33), by an
+// unpivoted L Dg L^T factorisation and one pair of triangular solves per row of D: ~110 fp64 instructions against the
+// ~1 500 of a cold Jacobi pseudo-inverse.  np.linalg.pinv (unscented.py:333) IS the inverse whenever no singular value
+// falls under 1e-15 of the largest, and both routes are backward stable, so they agree to ~cond(A) * 2^-52.  Returns
+// true ("bad") when a pivot is not safely away from zero (or anything is NaN): the caller then takes the eigenvalue
+// route, which also reproduces pinv's rank decisions.
+constexpr double kLdlPivotTol = 1e-9;
+__device__ __forceinline__ bool ldl_right_solve4(const double (&au)[10], const double (&D)[4][4], double (&K)[4][4]) {
+    const double a00 = au[0], a01 = au[1], a02 = au[2], a03 = au[3], a11 = au[4], a12 = au[5], a13 = au[6], a22 = au[7],
+                 a23 = au[8], a33 = au[9];
+    const double scale = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fabs(a33)));
+    const double d0 = a00, i0 = rcp_refined(d0);
+    const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
+    const double d1 = fma(-l10, a01, a11), i1 = rcp_refined(d1);
+    const double t21 = fma(-l20, a01, a12), t31 = fma(-l30, a01, a13);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = fma(-l21, t21, fma(-l20, a02, a22)), i2 = rcp_refined(d2);
+    const double t32 = fma(-l31, t21, fma(-l30, a02, a23));
+    const double l32 = t32 * i2;
+    const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a03, a33))), i3 = rcp_refined(d3);
+    const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
+    const bool bad = !(dmin > kLdlPivotTol * scale);  // also true for NaN anywhere
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {  // row r of K solves A k = (row r of D)^T
+        const double y0 = D[r][0];
+        const double y1 = fma(-l10, y0, D[r][1]);
+        const double y2 = fma(-l21, y1, fma(-l20, y0, D[r][2]));
+        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, D[r][3])));
+        const double x3 = y3 * i3;
+        const double x2 = fma(-l32, x3, y2 * i2);
+        const double x1 = fma(-l31, x3, fma(-l21, x2, y1 * i1));
+        const double x0 = fma(-l30, x3, fma(-l20, x2, fma(-l10, x1, y0 * i0)));
+        K[r][0] = x0;
+        K[r][1] = x1;
+        K[r][2] = x2;
+        K[r][3] = x3;
+    }
+    return bad;
+}
+
 // C = A * B (4x4)
 __device__ __forceinline__ void mm(const double (&A)[4][4], const double (&B)[4][4], double (&C)[4][4]) {
     STE_UNROLL

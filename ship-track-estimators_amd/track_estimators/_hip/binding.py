@@ -17,12 +17,17 @@ LIB_PATH = os.environ.get("STE_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libs
 STE_FLAG_SHARED_P0 = 0x1
 STE_FLAG_NO_INITIAL_UPDATE = 0x2
 STE_FLAG_ROBUST = 0x4
-STE_FLAG_SMOOTHER_LANE_PER_TRACK = 0x8
+STE_FLAG_LANES_1 = 0x10
+STE_FLAG_LANES_4 = 0x20
+
+STE_RTS_WORK_ROWS = 22  # doubles per (step, track) of ste_ukf_batch_f64.rts_work
 
 STE_STATUS_NAN = 0x1
 STE_STATUS_CLAMPED = 0x2
 STE_STATUS_NOCONV = 0x4
 STE_STATUS_ROBUST_CAP = 0x8
+STE_STATUS_HOST_INDEX = 0x10
+STE_STATUS_BAD_INDEX = 0x20
 
 _dp = C.c_void_p  # device / host pointers travel as integers
 
@@ -36,7 +41,7 @@ class SteUkfBatchF64(C.Structure):
         ("Tmax", C.c_int32),
         ("n", C.c_int32),
         ("flags", C.c_uint32),
-        ("reserved", C.c_int32),
+        ("tuning", C.c_int32),
         ("fan_scale", C.c_double),
         ("w0", C.c_double),
         ("wi", C.c_double),
@@ -138,7 +143,6 @@ SYMBOLS = {
     "ste_gp_lml_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_void_p]),
     "ste_gp_lml_subset_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, C.c_void_p]),
     "ste_gp_predict_f64": (C.c_int, [C.POINTER(SteGpBatchF64), C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
-    "ste_set_lanes_per_track": (C.c_int, [C.c_int]),
     "ste_stream_create_cu_range": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "ste_stream_destroy": (C.c_int, [C.c_void_p]),
 }

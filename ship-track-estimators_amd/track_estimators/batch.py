@@ -125,6 +125,7 @@ class HostBatch:
     chi_alpha: float = 50.0
     host_status: Optional[np.ndarray] = None  # (B,) int32 bits set while packing (STATUS_HOST_INDEX)
     order: Optional[np.ndarray] = None  # (B,) batch slot -> index of the caller's track (length-bucketed packing)
+    lanes: Optional[int] = None  # forward-kernel lane mapping for this batch: 1, 4, 0 = by batch size; None = default_lanes
 
     @property
     def shared_p0(self) -> bool:
@@ -143,7 +144,11 @@ def _as44(M, name):
     return M
 
 
-STATUS_HOST_INDEX = 0x10  # the reference would raise IndexError for this track (update index past the last observation)
+STATUS_HOST_INDEX = binding.STE_STATUS_HOST_INDEX  # the reference would raise IndexError for this track (update index past the last observation)
+
+# Lane mapping used by batches that do not name one (HostBatch.lanes is None): 0 = the library picks by batch size.
+# A per-call flag of the C ABI underneath (STE_FLAG_LANES_1 / _4); the tests set this to run every case in both mappings.
+default_lanes = 0
 
 
 def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, R, P0, t0s=None,
@@ -300,7 +305,8 @@ class DeviceBatch:
     _IN = ("nsteps", "x0", "P0", "dt", "sog_rate", "cog_rate", "sog_rate_rts", "cog_rate_rts", "upd_idx", "z",
            "noise_pred", "noise_upd", "noise_rts")
 
-    def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True, fuse_gains: bool = True):
+    def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True, fuse_gains: bool = True,
+                 tuning: int = 0):
         import torch
 
         self.lib = binding.require_gpu()
@@ -321,14 +327,18 @@ class DeviceBatch:
         # workspace for the smoother gains the forward pass can produce on the way (include/ste.h: rts_work)
         self.rts_work = None
         if alloc_smoothed and fuse_gains and hb.sog_rate_rts is None and hb.cog_rate_rts is None and N > 0:
-            self.rts_work = torch.empty((N, 30, B), **f64)
+            self.rts_work = torch.empty((N, binding.STE_RTS_WORK_ROWS, B), **f64)
         fan_scale, w0, wi = sigma_constants(4, hb.weights_computed)
         self._keep = (hb.H, hb.Q, hb.R)
         s = binding.SteUkfBatchF64()
         s.B, s.Nmax, s.Tmax, s.n = B, N, hb.Tmax, 4
+        lanes = default_lanes if hb.lanes is None else hb.lanes
+        if lanes not in (0, 1, 4):
+            raise ValueError(f"lanes must be 0 (automatic), 1 or 4, got {lanes!r}")
         s.flags = (binding.STE_FLAG_SHARED_P0 if hb.shared_p0 else 0) | (
             0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE) | (
-            binding.STE_FLAG_ROBUST if hb.robust else 0)
+            binding.STE_FLAG_ROBUST if hb.robust else 0) | {0: 0, 1: binding.STE_FLAG_LANES_1, 4: binding.STE_FLAG_LANES_4}[lanes]
+        s.tuning = int(tuning)
         s.chi_alpha, s.robust_max_iter = float(hb.chi_alpha), 50
         s.fan_scale, s.w0, s.wi = fan_scale, w0, wi
         s.H, s.Q, s.R = hb.H.ctypes.data, hb.Q.ctypes.data, hb.R.ctypes.data
@@ -383,33 +393,41 @@ class SmootherPipeline:
     latency-bound smoother.  Run back to back they leave most of the chip idle; run side by side on ordinary streams
     they land on the same SIMDs and take each other's issue slots.  Here forward passes run on streams restricted to
     the first ``forward_cus`` compute units and smoothers on streams restricted to the rest
-    (``ste_stream_create_cu_range``).  The forward kernel needs at most 256 VGPRs, so two forward passes share the
-    forward partition with two waves per SIMD -- a lone wave can use only half of the fp64 pipe's issue slots -- and the
+    (``ste_stream_create_cu_range``).  The forward kernel needs at most 256 VGPRs, so forward passes share the forward
+    partition with two waves per SIMD -- a lone wave can use only half of the fp64 pipe's issue slots -- and the
     smoothers of two batches share the smoother partition, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
     its histories and work rows; a batch is not resubmitted before its previous smoother has finished (events), so the
-    caller rotates through ``depth + 1`` or more of them (``buffers_needed``).
+    caller rotates through ``buffers_needed`` or more of them.
 
-        pipe = SmootherPipeline(device)
-        dbs = [DeviceBatch(hb, device) for _ in range(pipe.buffers_needed)]
-        for k in range(nbatches):
-            pipe.submit(dbs[k % len(dbs)], final=(k == nbatches - 1))
-        pipe.synchronize()
+        with SmootherPipeline(device, ntracks=hb.B) as pipe:
+            dbs = [DeviceBatch(hb, device) for _ in range(pipe.buffers_needed)]
+            for k in range(nbatches):
+                pipe.submit(dbs[k % len(dbs)], final=(k == nbatches - 1))
+            pipe.synchronize()
+
+    The CU-masked streams are destroyed by ``close()`` (the context manager, ``__del__``, and at the latest an atexit
+    hook): left to the HIP runtime's static destructors they outlive any profiler tool.
     """
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
-                 smoother_lane_per_track: bool = False, forward_streams: int = 2, smoother_streams: int = 2):
+                 forward_streams: Optional[int] = None, smoother_streams: int = 2):
         import torch
 
         self.torch = torch
-        self.smoother_lane_per_track = bool(smoother_lane_per_track)
         self.lib = binding.require_gpu()
         self.device = torch.device(device)
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
         if forward_cus is None:
-            # room for every forward wave of an ``ntracks`` batch at one wave per SIMD (a quad per track), counted per
-            # XCD because workgroups are dealt round-robin over the 8 XCDs; default: BASELINE's 10 000 tracks
+            # Three quarters of the chip for the forward passes (192 of 256 CUs, 24 per XCD).  The smoother moves ~500 B
+            # per track-step at ~28 GB/s per CU whatever the partition size, ~90 CU-ms per 10 000 x 500 batch, against
+            # ~280 CU-ms of forward pass; below a quarter of the chip its workgroups (two per CU) no longer fit in one
+            # round and it becomes the bottleneck (measured: 1.57 ms per step at 192 + 64, 2.3 ms at 200 + 56).
+            forward_cus = (ncu * 3 // 4) // 8 * 8
+        if forward_streams is None:
+            # as many forward passes in flight as fill the partition's wave slots (two per SIMD: the kernel holds 256
+            # VGPRs), rounded up -- the waves of the last pass start as slots come free -- and at most three
             waves = -(-(ntracks or 10_000) * 4 // 64)
-            forward_cus = 8 * -(-(-(-waves // 8)) // 4)
+            forward_streams = max(1, min(3, -(-forward_cus * 8 // waves)))
         if not (0 < forward_cus < ncu):
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
@@ -482,17 +500,7 @@ class SmootherPipeline:
         bwd_stream.wait_event(ready)
         if timing is not None:
             timing[2].record(bwd_stream)
-        # on its partition the smoother has fewer SIMD slots than a quad-per-track recurrence has waves: one lane per
-        # track (a quarter of the waves) finishes sooner there (1.95 vs 2.39 ms at 10 000 tracks on 96 CUs).  Opt-in:
-        # the two lane mappings round differently (1e-13), and the default keeps pipelined results bit-identical to
-        # a batch run on its own.
-        flags = db.struct.flags
-        if self.smoother_lane_per_track and not final:
-            db.struct.flags = flags | binding.STE_FLAG_SMOOTHER_LANE_PER_TRACK
-        try:
-            db.backward(bwd_stream)
-        finally:
-            db.struct.flags = flags
+        db.backward(bwd_stream)
         if timing is not None:
             timing[3].record(bwd_stream)
         if after_smoother is not None:

@@ -338,6 +338,45 @@ def modern_cases():
     return out
 
 
+def modern_robust_cases():
+    """BASELINE configs[3] as written ("Mahalanobis outlier rejection on"): the two modern ships the reference can
+    filter at all (modern_cases), run through ``_RobustUKF``; sampled rows as in modern_cases, plus how many updates were
+    rescaled at all (criterion above chi_alpha = 50 on entry)."""
+    csv = "/root/reference/data/modern_ships/modern_ship_data.csv"
+    H = np.diag([1, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6]); P = np.eye(4)
+    out = {}
+    ids = ["AMOUK05", "WCE5063"]
+    for sid in ids:
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.read_csv(csv, ship_id=sid, id_col="id", lat_col="lat", lon_col="lon")
+        st.get_measurements(include_sog=True, include_cog=True)
+        st.calculate_cog_rate()
+        st.calculate_sog_rate()
+        x0 = st.z[:, 0].reshape(-1, 1).copy()
+        ukf = _RobustUKF(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
+        rescaled = [0]
+        orig = ukf.scale_measurement_uncertainty
+
+        def counting(Rm, lam, _o=orig, _r=rescaled):
+            _r[0] += 1
+            return _o(Rm, lam)
+
+        ukf.scale_measurement_uncertainty = counting
+        dt = generate_dts(st.dts, 2)
+        N = len(dt)
+        with NoisePatch("zero"):
+            means, covs = ukf.run(nsteps=N, dt=dt, ship_track=st)
+            sm, sc = ukf.run_rts_smoother(ship_track=copy.deepcopy(st))
+        rows = np.unique(np.concatenate([np.arange(0, N + 1, 50), np.arange(N - 19, N + 1)]))
+        out[f"{sid}_rows"] = rows
+        out[f"{sid}_rescalings"] = np.int64(rescaled[0])
+        for k, v in (("means", means), ("covs", covs), ("means_smoothed", sm), ("covs_smoothed", sc)):
+            out[f"{sid}_{k}"] = v[rows]
+        print(f"modern robust {sid}: N={N} rescalings={rescaled[0]}")
+    out["ids"] = np.array(ids)
+    return out
+
+
 def two_runs_case():
     """A second ``run`` on the same filter object appends to the history and keeps the running time
     (kalman_filter.py:22-31,98): the update index restarts at 0 while ``self.time`` continues, so the float-equality
@@ -505,16 +544,18 @@ def main():
     np.savez_compressed(os.path.join(HERE, "modern_ships.npz"), **modern_cases())
     np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **robust_cases())
+    np.savez_compressed(os.path.join(HERE, "modern_ships_robust.npz"), **modern_robust_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz")}
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py robust prep ...
         for name in sys.argv[1:]:
-            fn = {"robust": robust_cases, "prep": prep_cases, "examples": example_cases}[name]
-            np.savez_compressed(os.path.join(HERE, {"robust": "robust.npz", "prep": "track_prep.npz",
-                                                    "examples": "batch_examples.npz"}[name]), **fn())
+            fn, fname = SELECTABLE[name]
+            np.savez_compressed(os.path.join(HERE, fname), **fn())
     else:
         main()

@@ -134,11 +134,7 @@ def test_robust_helpers_and_flag():
     np.testing.assert_allclose(out["means"][0], plain["means"][0], rtol=1e-9)  # clean tracks are untouched
 
 
-@pytest.mark.gpu
-def test_config4_modern_ships_batch():
-    """All seven ids of data/modern_ships in one ragged batch (13 274 .. 19 236 steps).  Two ships run clean and must
-    match the reference; five contain duplicate timestamps (dt = 0): the reference dies with LinAlgError inside pinv,
-    the batch flags them with STE_STATUS_NAN and carries on (like the batch example's try/except/continue)."""
+def _modern_batch(robust):
     from track_estimators import batch
     from track_estimators.ship_track import ShipTrack
     from track_estimators.utils import generate_dts, haversine_formula, heading
@@ -162,7 +158,30 @@ def test_config4_modern_ships_batch():
             dts.append(generate_dts(st.dts, 2))
             x0s.append(z[:, 0])
     hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P)
-    out = batch.run_batch(hb)
+    hb.robust = robust
+    return g, ids, batch.run_batch(hb)
+
+
+def _check_against(out, b, sid, g, max_row):
+    rows = g[f"{sid}_rows"]
+    keep = rows <= min(max_row, rows.max())
+    assert keep.sum() >= 140
+    for key in ("means", "means_smoothed"):
+        ref = g[f"{sid}_{key}"][keep]
+        err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.maximum(np.abs(ref), 1e-3))
+        assert err < 1e-6, (sid, key, err)
+    for key in ("covs", "covs_smoothed"):
+        ref = g[f"{sid}_{key}"][keep]
+        err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.max(np.abs(ref), axis=(-1, -2), keepdims=True))
+        assert err < 1e-5, (sid, key, err)
+
+
+@pytest.mark.gpu
+def test_config4_modern_ships_batch():
+    """All seven ids of data/modern_ships in one ragged batch (13 274 .. 19 236 steps).  Two ships run clean and must
+    match the reference; five contain duplicate timestamps (dt = 0): the reference dies with LinAlgError inside pinv,
+    the batch flags them with STE_STATUS_NAN and carries on (like the batch example's try/except/continue)."""
+    g, ids, out = _modern_batch(robust=False)
     # AMOUK05 sits in port for months; from about step 7 200 the filter itself runs away on that data (latitude passes
     # 92 degrees, speeds of -190..160 km/h) and the trajectory becomes chaotic: two CPU restatements of the reference
     # that differ only in the square-root algorithm end up 220 degrees of longitude apart.  Parity is therefore checked on
@@ -172,19 +191,29 @@ def test_config4_modern_ships_batch():
     for b, sid in enumerate(ids):
         if int(g[f"{sid}_ok"]):
             assert not (out["status"][b] & 0x1)
-            rows = g[f"{sid}_rows"]
-            keep = rows <= stable_rows.get(sid, rows.max())
-            assert keep.sum() >= 140
-            for key in ("means", "means_smoothed"):
-                ref = g[f"{sid}_{key}"][keep]
-                err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.maximum(np.abs(ref), 1e-3))
-                assert err < 1e-6, (sid, key, err)
-            for key in ("covs", "covs_smoothed"):
-                ref = g[f"{sid}_{key}"][keep]
-                err = np.max(np.abs(out[key][b, rows[keep]] - ref) / np.max(np.abs(ref), axis=(-1, -2), keepdims=True))
-                assert err < 1e-5, (sid, key, err)
+            _check_against(out, b, sid, g, stable_rows.get(sid, 1 << 30))
         else:
             assert out["status"][b] & 0x11, sid  # non-finite state and/or update index past the last observation
+
+
+@pytest.mark.gpu
+def test_config4_modern_ships_robust_on():
+    """BASELINE configs[3] as written -- Mahalanobis outlier rejection ON: the same ragged batch with STE_FLAG_ROBUST,
+    against the reference run with its check_robustness call site enabled (tests/golden/modern_ships_robust.npz; the two
+    ships the reference can filter at all; 1 861 and 38 419 updates get their R rescaled).  The five ships with
+    duplicate timestamps are flagged as before."""
+    g, ids, out = _modern_batch(robust=True)
+    gr = np.load(os.path.join(GOLDEN, "modern_ships_robust.npz"))
+    assert int(gr["WCE5063_rescalings"]) > 1000
+    stable_rows = {"AMOUK05": 7000}
+    for b, sid in enumerate(ids):
+        if sid in [str(s) for s in gr["ids"]]:
+            assert not (out["status"][b] & 0x1)
+            _check_against(out, b, sid, gr, stable_rows.get(sid, 1 << 30))
+            plain = g[f"{sid}_means"]
+            assert np.abs(gr[f"{sid}_means"] - plain).max() > 1e-3  # the robust reference run differs from the plain one
+        else:
+            assert out["status"][b] & 0x11, sid
 
 
 @pytest.mark.gpu

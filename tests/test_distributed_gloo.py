@@ -92,3 +92,66 @@ def test_two_rank_gather_matches_single_process():
         for r in range(world):
             rlo, rhi = r * (total // world), (r + 1) * (total // world)
             assert np.array_equal(g[r], ref[:, :2, rlo:rhi])  # every rank sees every shard, in rank order
+
+
+def _oracle_smoothed(sb, substeps):
+    """The real filter + smoother arithmetic on a CPU-sized shard, through the oracle: sm_mean laid out [N+1][4][B]."""
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    hb = batch.pack_uniform(sb, substeps, H, Q, R, P0)
+    fires = hb.upd_idx.T >= 0
+    zidx = np.where(fires, hb.upd_idx.T, 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    T = sb.lon.shape[1]
+    m, P = orc.forward_batch(hb.x0.T, P0, H, Q, R, hb.dt.T, fires, zidx, ridx, sb.z, sb.sog_rate, sb.cog_rate)
+    rr = np.broadcast_to(batch.rts_rate_index(hb.Nmax + 1, T - 1, T), (hb.B, hb.Nmax))
+    sm, _ = orc.backward_batch(m, P, Q, hb.dt.T, rr, sb.sog_rate, sb.cog_rate)
+    return np.ascontiguousarray(sm.transpose(1, 2, 0))
+
+
+def _worker_uneven(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from track_estimators import distributed, synthetic
+
+        lo, hi = distributed.shard_bounds(total, rank, world)
+        bmax = -(-total // world)
+        sb = synthetic.make_batch(hi - lo, nobs=6, gap_h=1.0, seed0=lo)  # seed = global track index
+        local = torch.from_numpy(_oracle_smoothed(sb, 2))
+        g = distributed.gather_smoothed_positions(local, pad_to=bmax)
+        og = distributed.OverlappedGather(local.shape[0], bmax, "cpu")
+        slot = og.launch(local)
+        og.finish()
+        assert torch.equal(og.result(slot), g)
+        q.put((rank, distributed.assemble_tracks(g, total).numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_uneven_split_real_arithmetic():
+    """13 tracks over 2 ranks (7 + 6): each rank filters and smooths its shard (the oracle stands in for the GPU), the
+    shards are padded to the larger one for the all-gather and cut back by assemble_tracks; every rank ends up with the
+    positions one process computes for the whole batch, bit for bit (a track does not depend on its shard)."""
+    from track_estimators import synthetic
+
+    total, world = 13, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    ref = _oracle_smoothed(synthetic.make_batch(total, nobs=6, gap_h=1.0, seed0=0), 2)[:, :2, :]
+    for rank, full in res:
+        assert full.shape == ref.shape
+        assert np.array_equal(full, ref)

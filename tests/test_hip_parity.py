@@ -18,13 +18,14 @@ COV_TOL = 1e-5
 
 @pytest.fixture(params=[1, 4, 0], ids=["lane-per-track", "quad-per-track", "auto"], autouse=True)
 def lanes_per_track(request):
-    """Every parity test runs with both forward-kernel lane mappings (include/ste.h: ste_set_lanes_per_track)."""
-    from track_estimators._hip import binding
+    """Every parity test runs with both forward-kernel lane mappings (include/ste.h: STE_FLAG_LANES_1 / _4, a per-call
+    flag; ``batch.default_lanes`` is what batches that do not name a mapping get)."""
+    from track_estimators import batch
 
-    lib = binding.load()
-    prev = lib.ste_set_lanes_per_track(request.param)
+    prev = batch.default_lanes
+    batch.default_lanes = request.param
     yield request.param
-    lib.ste_set_lanes_per_track(prev)
+    batch.default_lanes = prev
 
 
 CASES = [("ukf_synthetic.npz", i) for i in range(10)] + [("ukf_edge.npz", i) for i in range(3)] + [
@@ -175,7 +176,6 @@ def test_full_size_batch_properties():
     sample of tracks matches the oracle."""
     from oracle import ukf_oracle as orc
     from track_estimators import batch, synthetic
-    from track_estimators._hip import binding
 
     H, Q, R, P0 = synthetic.example_matrices()
     nuniq, B = 2500, 10_000
@@ -184,10 +184,9 @@ def test_full_size_batch_properties():
     sb = synthetic.SyntheticBatch(**{f.name: getattr(sbu, f.name)[idx] for f in __import__("dataclasses").fields(sbu)})
     hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
     assert hb.B == B and hb.Nmax == 500
-    lib = binding.load()
     res = {}
     for lanes in (1, 4):
-        lib.ste_set_lanes_per_track(lanes)
+        hb.lanes = lanes
         db = batch.DeviceBatch(hb)
         db.run()
         db.torch.cuda.synchronize()

@@ -122,3 +122,38 @@ def test_robust_helpers_vs_reference():
         assert np.isclose(c, k["rb_ci"][i], rtol=1e-12)
         lam = orc.update_lambda_factor(k["rb_x"][i], k["H"], 1.0, c, 50.0, k["rb_z"][i], k["rb_P"][i], k["R"])
         assert np.isclose(lam, k["rb_lambda"][i], rtol=1e-12)
+
+
+def test_check_robustness_vs_reference():
+    """oracle.check_robustness against direct calls of the reference's check_robustness (noise zeroed): the rescaled R
+    bit for bit and the same number of loop iterations, for outliers needing 0 .. 6 rescalings, diagonal and dense R."""
+    import os
+
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "robust.npz"))
+    assert g["cr_iters"].max() >= 5 and (g["cr_iters"] == 0).sum() >= 3
+    for i in range(len(g["cr_x"])):
+        H = g["H"] if i < int(g["cr_dense_from"]) else np.eye(4)
+        Rr, it = orc.check_robustness(g["cr_x"][i], H, g["cr_z"][i], g["cr_P"][i], g["cr_R"][i], return_iters=True)
+        assert it == int(g["cr_iters"][i])
+        assert np.array_equal(Rr, g["cr_Rout"][i]), i
+
+
+def test_robust_runs_vs_reference():
+    """Whole robust tracks (reference run with its check_robustness call site enabled, tests/golden/make_golden.py
+    ``_RobustUKF``): the oracle's forward_track(robust=True) + backward_track reproduce them bit for bit."""
+    import os
+
+    from conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "robust.npz"))
+    for ci in range(int(g["nruns"])):
+        z, dts = g[f"run{ci}_z"], g[f"run{ci}_dts"]
+        m, P = orc.forward_track(z[:, 0], g["P0"], g["H"], g["Q"], g["R"], g[f"run{ci}_dt"], dts, z,
+                                 g[f"run{ci}_sog_rate"], g[f"run{ci}_cog_rate"], robust=True)
+        assert np.array_equal(m, g[f"run{ci}_means"]) and np.array_equal(P, g[f"run{ci}_covs"])
+        assert np.abs(m[:, 0] - g[f"run{ci}_plain_means"][:, 0]).max() > 1.0  # the robust path really differs
+        sm, sP = orc.backward_track(m, P, g["Q"], g[f"run{ci}_dt"], len(dts), g[f"run{ci}_sog_rate"],
+                                    g[f"run{ci}_cog_rate"])
+        assert np.array_equal(sm, g[f"run{ci}_means_smoothed"]) and np.array_equal(sP, g[f"run{ci}_covs_smoothed"])

@@ -54,21 +54,22 @@ def test_pipeline_hooks_and_timing_events():
     with pytest.raises(ValueError):
         batch.SmootherPipeline("cuda:0", forward_cus=10_000)
     pipe.close()
-    # opt-in: lane-per-track recurrence on the smoother partition (different rounding, same answer)
-    ref = dbs[0].sm_mean.clone()
-    pipe = batch.SmootherPipeline("cuda:0", forward_cus=160, smoother_lane_per_track=True)
-    pipe.submit(dbs[0])
-    pipe.submit(dbs[1], final=True)
-    pipe.synchronize()
-    assert float((dbs[0].sm_mean - ref).abs().max() / ref.abs().max()) < 1e-10
-    assert dbs[0].struct.flags & 0x8 == 0  # the flag is not left behind on the batch
+    # closing is idempotent, a closed pipeline refuses work, and the context manager closes on the way out
     pipe.close()
+    assert pipe.closed
+    with pytest.raises(RuntimeError):
+        pipe.submit(dbs[0])
+    ref = dbs[0].sm_mean.clone()
+    with batch.SmootherPipeline("cuda:0", forward_cus=160) as pipe2:
+        pipe2.submit(dbs[0])  # the event the closed pipeline left on the batch is gone: no wait on a dead stream
+        pipe2.submit(dbs[1], final=True)
+        pipe2.synchronize()
+    assert pipe2.closed and torch.equal(dbs[0].sm_mean, ref)
 
 
 def test_pipeline_full_size_matches_serial():
     """BASELINE.json configs[1] at full size (10 000 tracks x 500 steps): six pipelined steps over two sets of buffers
-    leave exactly the bits one batch run on its own leaves; with the lane-per-track recurrence on the smoother partition
-    (what bench.py uses) the smoothed states agree to rounding."""
+    leave exactly the bits one batch run on its own leaves."""
     import torch
 
     H, Q, R, P0 = synthetic.example_matrices()
@@ -78,7 +79,7 @@ def test_pipeline_full_size_matches_serial():
     ref.run()
     torch.cuda.synchronize()
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert (pipe.forward_cus, pipe.smoother_cus) == (160, 96) and pipe.buffers_needed == 5
+    assert pipe.forward_cus + pipe.smoother_cus == 256 and pipe.buffers_needed == len(pipe.fwd_streams) + len(pipe.bwd_streams) + 1
     dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
     for k in range(8):
         pipe.submit(dbs[k % 3], final=(k == 7))
@@ -88,12 +89,38 @@ def test_pipeline_full_size_matches_serial():
         assert torch.equal(db.sm_mean, ref.sm_mean) and torch.equal(db.sm_cov, ref.sm_cov)
         assert not db.status_host().any()
     pipe.close()
-    pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B, smoother_lane_per_track=True)
-    for k in range(6):
-        pipe.submit(dbs[k % 3], final=(k == 5))
-    pipe.synchronize()
+
+
+def test_pipeline_config2_shard_size():
+    """BASELINE.json configs[2]'s shard (100 000 tracks / 8 GPUs = 12 500 tracks x 500 steps) through the default
+    pipeline for that size: the partition is the measured one (192 + 64 CUs, two forward passes in flight), seven
+    pipelined steps leave exactly the bits of a batch run on its own, and a sample of tracks matches the oracle."""
+    import torch
+    from oracle import ukf_oracle as orc
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(12_500, nobs=126, gap_h=1.0, seed0=87_500)  # the last shard of the 100 000-track job
+    hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    ref = batch.DeviceBatch(hb)
+    ref.run()
+    torch.cuda.synchronize()
+    with batch.SmootherPipeline("cuda:0", ntracks=hb.B) as pipe:
+        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (192, 64, 2, 2)
+        dbs = [batch.DeviceBatch(hb) for _ in range(pipe.buffers_needed)]
+        for k in range(7):
+            pipe.submit(dbs[k % len(dbs)], final=(k == 6))
+        pipe.synchronize()
     for db in dbs:
-        assert torch.equal(db.fwd_mean, ref.fwd_mean)
-        err = (db.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
-        assert float(err.max()) < 1e-9
-    pipe.close()
+        assert torch.equal(db.sm_mean, ref.sm_mean) and torch.equal(db.sm_cov, ref.sm_cov)
+        assert torch.equal(db.fwd_mean, ref.fwd_mean) and not db.status_host().any()
+    n = 24
+    fires = hb.upd_idx.T[:n] >= 0
+    zidx = np.where(fires, hb.upd_idx.T[:n], 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
+    rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (n, 500))
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
+    got = ref.sm_mean[:, :, :n].permute(2, 0, 1).cpu().numpy()
+    assert float(np.max(np.abs(got - sm) / np.maximum(np.abs(sm), 1e-12))) < 1e-6
+    gotP = ref.sm_cov[:, :, :n].permute(2, 0, 1).cpu().numpy().reshape(n, 501, 4, 4)
+    assert float(np.max(np.abs(gotP - sP) / np.max(np.abs(sP), axis=(-1, -2), keepdims=True))) < 1e-5
