@@ -1018,7 +1018,10 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
     hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, ns), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(ns), dim3(256), 0, s, p);
-    if (ns >= 128)
+    // chosen by the size of the BATCH, not of this launch: a subset launch must leave the bits a full launch leaves
+    // (include/ste.h: "per-matrix results do not depend on which other matrices are listed"), and the two inverse kernels
+    // sum in different orders
+    if (p.B >= 128)
         hipLaunchKernelGGL(stegp::gp_trtri_cols, dim3(ns), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(stegp::gp_trtri_rows, dim3(p.nb_max, ns), dim3(256), 0, s, p);

@@ -368,18 +368,42 @@ class DeviceBatch:
         binding.check(self.lib.ste_ukf_urtss_f64(C.byref(self.struct), self._stream(stream)), "ste_ukf_urtss_f64")
 
     # -- results ------------------------------------------------------------------------------------------------
+    _OUT = {"means": ("fwd_mean", 4), "covs": ("fwd_cov", 16), "means_smoothed": ("sm_mean", 4),
+            "covs_smoothed": ("sm_cov", 16)}
+
+    def download(self, names=("means", "covs", "means_smoothed", "covs_smoothed"), track_index=None):
+        """Histories as NumPy arrays shaped like the reference's return values, track first: ``means*`` (B, Nmax+1, 4),
+        ``covs*`` (B, Nmax+1, 4, 4); rows past nsteps[b] are padding.  ``track_index`` (device int64 tensor) reorders /
+        selects tracks on the device.  Each tensor is transposed on the device (one pass at HBM speed) and copied into
+        page-locked host memory with an asynchronous copy; the arrays returned are views of that memory (PyTorch's
+        host allocator recycles it once they are dropped, so only a process's first large download pays for pinning).
+        10 000 x 500 with all four histories: 1.6 GB, ~35 ms over PCIe gen 5 instead of ~170 ms through pageable memory."""
+        torch = self.torch
+        out, pending = {}, []
+        for name in names:
+            attr, width = self._OUT[name]
+            t = getattr(self, attr)
+            if t is None:
+                raise ValueError(f"{name} was not computed for this batch (alloc_smoothed=False)")
+            if track_index is not None:
+                t = t.index_select(2, track_index)
+            dev_t = t.permute(2, 0, 1).contiguous()  # (B, N+1, width) on the device
+            host = torch.empty(dev_t.shape, dtype=dev_t.dtype, pin_memory=True)
+            host.copy_(dev_t, non_blocking=True)
+            pending.append(dev_t)  # keep the source alive until the copy has run
+            a = host.numpy()
+            out[name] = a.reshape(a.shape[0], a.shape[1], 4, 4) if width == 16 else a
+        torch.cuda.current_stream(self.device).synchronize()
+        return out
+
     def filtered(self):
         """(means (B, Nmax+1, 4), covs (B, Nmax+1, 4, 4)) as NumPy arrays (rows past nsteps[b] are padding)."""
-        B, N = self.hb.B, self.hb.Nmax
-        m = self.fwd_mean.permute(2, 0, 1).contiguous().cpu().numpy()
-        P = self.fwd_cov.permute(2, 0, 1).contiguous().cpu().numpy().reshape(B, N + 1, 4, 4)
-        return m, P
+        d = self.download(("means", "covs"))
+        return d["means"], d["covs"]
 
     def smoothed(self):
-        B, N = self.hb.B, self.hb.Nmax
-        m = self.sm_mean.permute(2, 0, 1).contiguous().cpu().numpy()
-        P = self.sm_cov.permute(2, 0, 1).contiguous().cpu().numpy().reshape(B, N + 1, 4, 4)
-        return m, P
+        d = self.download(("means_smoothed", "covs_smoothed"))
+        return d["means_smoothed"], d["covs_smoothed"]
 
     def status_host(self):
         return self.status.cpu().numpy()
@@ -646,8 +670,10 @@ def prepare_ship_tracks(ship_tracks: Sequence, device="cuda:0"):
     return ship_tracks
 
 
-def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True):
-    """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays."""
+def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True, outputs=None):
+    """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays (tracks in the caller's
+    order).  ``outputs``: which histories to bring back -- any of "means", "covs", "means_smoothed", "covs_smoothed"
+    (default: all that were computed); "status" and "nsteps" always come along."""
     db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains)
     if smooth:
         if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts[:, (hb.host_status == 0) if hb.host_status is not None else slice(None)]).any():
@@ -655,15 +681,16 @@ def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: b
         db.run()
     else:
         db.forward()
-    db.torch.cuda.synchronize(db.device)
-    out = {"status": db.status_host(), "nsteps": hb.nsteps.copy()}
-    if hb.host_status is not None:
-        out["status"] = out["status"] | hb.host_status
-    out["means"], out["covs"] = db.filtered()
-    if smooth:
-        out["means_smoothed"], out["covs_smoothed"] = db.smoothed()
-    if hb.order is not None:  # back to the caller's track order
+    if outputs is None:
+        outputs = ("means", "covs") + (("means_smoothed", "covs_smoothed") if smooth else ())
+    inv = None
+    if hb.order is not None:  # back to the caller's track order, on the device
         inv = np.empty_like(hb.order)
         inv[hb.order] = np.arange(len(hb.order))
-        out = {k: v[inv] for k, v in out.items()}
+    out = db.download(outputs, None if inv is None else db.torch.from_numpy(inv).to(db.device))
+    status = db.status_host()
+    if hb.host_status is not None:
+        status = status | hb.host_status
+    nsteps = hb.nsteps.copy()
+    out["status"], out["nsteps"] = (status, nsteps) if inv is None else (status[inv], nsteps[inv])
     return out

@@ -26,6 +26,7 @@ class GpDeviceBatch:
         self.B = len(xs)
         if self.B == 0:
             raise ValueError("empty batch")
+        self._xs, self._ys, self._jitter = list(xs), list(ys), float(jitter)
         self.n = np.array([len(x) for x in xs], dtype=np.int32)
         self.nout = int(np.asarray(ys[0]).reshape(len(xs[0]), -1).shape[1])
         self.nmax = int(self.n.max())
@@ -66,6 +67,16 @@ class GpDeviceBatch:
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def bytes_per_track(self) -> int:
+        """HBM held per track by this batch (K, U and the small arrays)."""
+        return 8 * (2 * self.ld * self.ld + self.nb * 64 * 64 + (self.nout + 2) * self.nmax + 3 * self.nb * (self.nb + 1) // 2)
+
+    def replicated(self, copies: int) -> "GpDeviceBatch":
+        """A batch holding ``copies`` consecutive copies of this one's tracks (entry c * B + b is track b): the optimiser
+        restarts of a fit run as extra batch entries that share their track's data."""
+        return GpDeviceBatch(self._xs * copies, self._ys * copies, device=self.device, jitter=self._jitter)
 
     def _set_theta(self, thetas):
         th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(self.B, 3))

@@ -123,9 +123,21 @@ def _minimize_lockstep(batch: GpDeviceBatch, starts: np.ndarray, bounds: np.ndar
     return out_theta, out_fun
 
 
+MAX_LOCKSTEP_ENTRIES = 1024  # optimisers advanced together (one Python thread each)
+RESTART_HBM_BUDGET = 96 << 30  # bytes of HBM a group of restarts may take beside the batch itself
+
+
 def fit_thetas(batch: GpDeviceBatch, theta0: np.ndarray, bounds: np.ndarray, n_restarts_optimizer: int, rng,
                optimizer="fmin_l_bfgs_b"):
-    """scikit-learn's GaussianProcessRegressor.fit procedure for every track of the batch (same start points)."""
+    """scikit-learn's GaussianProcessRegressor.fit procedure for every track of the batch: L-BFGS-B from the kernel's
+    theta, then ``n_restarts_optimizer`` more runs from log-uniform starts, best optimum kept (first one wins a tie, as
+    in scikit-learn's loop).  ``rng``: one RandomState shared by the batch (starts drawn restart by restart, in track
+    order) or a list of one RandomState per track (each track then sees exactly the stream a fit of its own would).
+
+    The restarts do not depend on one another, so they run as extra batch entries that share their track's data: all
+    (restarts + 1) x B optimisers advance in lock-step, one batched device launch per round, in groups bounded by HBM
+    (``RESTART_HBM_BUDGET``) and by ``MAX_LOCKSTEP_ENTRIES`` -- instead of 51 sequential lock-step fits for the
+    reference's default of 50 restarts (gaussian_process.py:50)."""
     B = batch.B
     if optimizer is None:
         thetas = np.tile(theta0, (B, 1))
@@ -133,16 +145,34 @@ def fit_thetas(batch: GpDeviceBatch, theta0: np.ndarray, bounds: np.ndarray, n_r
         return thetas, lml
     if optimizer != "fmin_l_bfgs_b":
         raise NotImplementedError("only optimizer='fmin_l_bfgs_b' or None are supported on the HIP GP path")
-    best_theta, best_fun = _minimize_lockstep(batch, np.tile(theta0, (B, 1)), bounds)
+    starts = [np.tile(theta0, (B, 1))]
     if n_restarts_optimizer > 0:
         if not np.isfinite(bounds).all():
             raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+        rngs = rng if isinstance(rng, (list, tuple)) else [rng] * B
         for _ in range(n_restarts_optimizer):
             # scikit-learn draws one start per restart and fit; a batch draws B of them in track order
-            starts = np.stack([rng.uniform(bounds[:, 0], bounds[:, 1]) for _ in range(B)])
-            th, fun = _minimize_lockstep(batch, starts, bounds)
-            better = fun < best_fun
-            best_theta[better], best_fun[better] = th[better], fun[better]
+            starts.append(np.stack([rngs[b].uniform(bounds[:, 0], bounds[:, 1]) for b in range(B)]))
+    per_group = max(1, min(len(starts), MAX_LOCKSTEP_ENTRIES // B, RESTART_HBM_BUDGET // max(1, batch.bytes_per_track * B)))
+    best_theta, best_fun = None, None
+    big = None
+    for g0 in range(0, len(starts), per_group):
+        group = starts[g0:g0 + per_group]
+        if len(group) == 1:
+            th, fun = _minimize_lockstep(batch, group[0], bounds)
+            th, fun = th[None], fun[None]
+        else:
+            if big is None or big.B != len(group) * B:
+                big = None  # release the previous group's buffers before the next allocation
+                big = batch.replicated(len(group))
+            th, fun = _minimize_lockstep(big, np.concatenate(group), bounds)
+            th, fun = th.reshape(len(group), B, 3), fun.reshape(len(group), B)
+        for r in range(len(group)):
+            if best_theta is None:
+                best_theta, best_fun = th[r].copy(), fun[r].copy()
+            else:
+                better = fun[r] < best_fun
+                best_theta[better], best_fun[better] = th[r][better], fun[r][better]
     return best_theta, -best_fun
 
 
@@ -248,7 +278,10 @@ class GPRegression:
         gpr_kwargs = dict(gpr_kwargs or {"n_restarts_optimizer": 50})
         data = [self._training_data(st) for st in ship_tracks]
         theta0, bounds = _kernel_spec(self._kernel)
-        rng = _check_random_state(gpr_kwargs.get("random_state"))
+        seed = gpr_kwargs.get("random_state")
+        # an integer seed means what it means for a loop of single fits (the reference's batch example builds one
+        # regressor per ship): every track gets its own stream from that seed
+        rng = [np.random.RandomState(seed) for _ in data] if isinstance(seed, (int, np.integer)) else _check_random_state(seed)
         self._batch = GpDeviceBatch([X[:, 0] for X, _ in data], [y for _, y in data],
                                     jitter=float(gpr_kwargs.get("alpha", 1e-10)))
         self._thetas, self._lml = fit_thetas(self._batch, theta0, bounds, int(gpr_kwargs.get("n_restarts_optimizer", 0)),

@@ -377,6 +377,111 @@ def modern_robust_cases():
     return out
 
 
+def prep_cases():
+    """Observation preparation: the reference's ShipTrack.calculate_cog / calculate_sog /
+    calculate_sog_rate / calculate_cog_rate / get_measurements(True, True) (ship_track.py:197-338) with its own pure-NumPy
+    sphere pair (utils.haversine_formula / heading) on 40 ragged random tracks (2 .. 90 observations) and on a track
+    with duplicate timestamps and coincident points (gap = 0 -> inf / NaN).  Arrays are padded to the longest track."""
+    rng = np.random.default_rng(11)
+    tracks = []
+    for _ in range(40):
+        T = int(rng.integers(2, 91))
+        lon = rng.uniform(-170, 170) + np.cumsum(rng.normal(0, 0.3, T))
+        lat = rng.uniform(-60, 60) + np.cumsum(rng.normal(0, 0.2, T))
+        dts = rng.choice([0.5, 1.0, 6.0, 23.0, 24.0, 25.0], T - 1)
+        tracks.append((lon, lat, dts))
+    lon = np.array([10.0, 10.2, 10.2, 10.5, 10.6, 10.9, 11.0, 11.0])
+    lat = np.array([50.0, 50.1, 50.1, 50.3, 50.3, 50.2, 50.2, 50.2])
+    tracks.append((lon, lat, np.array([1.0, 0.0, 2.0, 1.0, 0.0, 1.0, 3.0])))  # zero gaps, moved and not moved
+    tracks.append((np.array([359.9, 0.1, 0.3, 359.8]), np.array([-0.1, 0.0, 0.1, 0.0]), np.array([1.0, 1.0, 2.0])))  # 0/360 seam
+    B, Tm = len(tracks), max(len(t[0]) for t in tracks)
+    out = {"nobs": np.array([len(t[0]) for t in tracks], dtype=np.int64)}
+    for k in ("lon", "lat", "dts", "sog", "cog", "sog_rate", "cog_rate"):
+        out[k] = np.zeros((B, Tm))
+    out["z"] = np.zeros((B, 4, Tm))
+    for b, (lo, la, d) in enumerate(tracks):
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.lon, st.lat, st.dts = lo.copy(), la.copy(), d.copy()
+        with np.errstate(all="ignore"):
+            st.calculate_cog()
+            st.calculate_sog()
+            st.calculate_sog_rate()
+            st.calculate_cog_rate()
+            z = st.get_measurements(include_sog=True, include_cog=True)
+        T = len(lo)
+        out["lon"][b, :T], out["lat"][b, :T], out["dts"][b, : T - 1] = lo, la, d
+        out["sog"][b, :T], out["cog"][b, :T] = st.sog, st.cog
+        out["sog_rate"][b, :T], out["cog_rate"][b, :T] = st.sog_rate, st.cog_rate
+        out["z"][b, :, :T] = z
+    print("prep: %d tracks, non-finite sog entries: %d" % (B, int((~np.isfinite(out["sog"])).sum())))
+    return out
+
+
+EXAMPLE_SEED_BASE = 20240000
+
+
+def example_cases():
+    """The compute part of the reference's two batch examples run as written (examples/example_ukf_rts_smoother_batch.py
+    :15-90, examples/example_gaussian_process_batch.py:15-55) on data/historical_ships, with two harness changes only:
+    the sphere pair (haversine_formula / heading) is injected because geographiclib is absent here, and the global
+    generator is seeded per ship (EXAMPLE_SEED_BASE + position in ``ids``) so that the injected noise can be replayed.
+    Recorded: the id list after ``ids.pop(1)``, what happened to each id (ok / skipped because dt > 48 / error), and for
+    every ok ship rows 0, N//2 and N of the filtered and smoothed histories.  GP: the fitted theta, the log marginal
+    likelihood and the predictions of the first 8 ships with n_restarts_optimizer = 2 and random_state = 0."""
+    import pandas as pd
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from track_estimators.gaussian_processes.gaussian_process import GPRegression
+
+    csv = "/root/reference/data/historical_ships/historical_ship_data.csv"
+    df = pd.read_csv(csv)
+    ids = df["primary.id"].unique().tolist()
+    ids.pop(1)
+    out = {"ids": np.array([str(i) for i in ids]), "seed_base": np.int64(EXAMPLE_SEED_BASE)}
+    cat = []
+    H = np.diag([1, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6])
+    P = np.diag([1.0, 1.0, 1.0, 1.0])
+    for i, sid in enumerate(ids):
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.read_csv(csv_file=csv, ship_id=sid, id_col="primary.id", lat_col="lat", lon_col="lon2", reverse=False)
+        z = st.get_measurements(include_sog=True, include_cog=True)
+        st.calculate_cog_rate()
+        st.calculate_sog_rate()
+        x0 = z[:, 0].reshape(-1, 1).copy()
+        ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
+        dt_array = generate_dts(st.dts, 2)
+        if dt_array.max() > 48:
+            cat.append("skipped")
+            continue
+        np.random.seed(EXAMPLE_SEED_BASE + i)
+        try:
+            m, c = ukf.run(nsteps=len(dt_array), dt=dt_array, ship_track=st)
+            sm, sc = ukf.run_rts_smoother(ship_track=st)
+        except Exception as exc:
+            cat.append("error")
+            print("example: error in", sid, type(exc).__name__)
+            continue
+        cat.append("ok")
+        N = len(dt_array)
+        rows = np.array([0, N // 2, N])
+        out[f"ukf_{i}_rows"] = rows
+        out[f"ukf_{i}_means"], out[f"ukf_{i}_covs"] = m[rows], c[rows]
+        out[f"ukf_{i}_means_smoothed"], out[f"ukf_{i}_covs_smoothed"] = sm[rows], sc[rows]
+    out["category"] = np.array(cat)
+    print("example ukf: %d ids, ok %d, skipped %d, error %d" % (len(ids), cat.count("ok"), cat.count("skipped"), cat.count("error")))
+    for i, sid in enumerate(ids[:8]):
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.read_csv(csv_file=csv, ship_id=sid, id_col="primary.id", lat_col="lat", lon_col="lon2", reverse=False)
+        gpr = GPRegression(kernel=1.0 * RBF() + WhiteKernel(noise_level=0.5))
+        model = gpr.fit(st, gpr_kwargs={"n_restarts_optimizer": 2, "random_state": 0})
+        times = np.insert(np.cumsum(generate_dts(st.dts, substeps=1)), 0, 0)
+        pred, std = gpr.predict(times=times)
+        out[f"gp_{i}_theta"] = model.kernel_.theta.copy()
+        out[f"gp_{i}_lml"] = np.float64(model.log_marginal_likelihood_value_)
+        out[f"gp_{i}_pred"], out[f"gp_{i}_std"] = pred, std
+    out["gp_count"] = np.int64(8)
+    return out
+
+
 def two_runs_case():
     """A second ``run`` on the same filter object appends to the history and keeps the running time
     (kalman_filter.py:22-31,98): the update index restarts at 0 while ``self.time`` continues, so the float-equality
@@ -545,12 +650,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **robust_cases())
     np.savez_compressed(os.path.join(HERE, "modern_ships_robust.npz"), **modern_robust_cases())
+    np.savez_compressed(os.path.join(HERE, "track_prep.npz"), **prep_cases())
+    np.savez_compressed(os.path.join(HERE, "batch_examples.npz"), **example_cases())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
-SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz")}
+SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
+              "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz")}
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py robust prep ...

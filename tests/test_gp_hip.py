@@ -173,3 +173,108 @@ def test_large_batch_kernels_match_small_batch_kernels_and_oracle():
         l, g, _, _ = gpo.lml_and_grad(theta[b], xs[b], ys[b])
         assert np.isclose(lml[b], l, rtol=1e-10, atol=1e-8)
         np.testing.assert_allclose(grad[b], g, rtol=1e-7, atol=1e-6)
+
+
+def _gp_tracks(rng, B, n):
+    xs, ys = [], []
+    for b in range(B):
+        x = np.insert(np.cumsum(rng.choice([0.5, 1.0, 2.0], n - 1)), 0, 0)
+        f = np.column_stack([np.sin(x / 90.0) + 0.002 * x, np.cos(x / 140.0)])
+        xs.append(x)
+        ys.append(f + rng.normal(0, 0.05, f.shape))
+    return xs, ys
+
+
+@pytest.mark.timeout(600)
+def test_objective_at_n2000_vs_oracle():
+    """BASELINE configs[4]'s matrix size (n = 2000: 32 tile columns) in a small batch, every track against the oracle
+    (SciPy LAPACK cholesky / cho_solve, the calls scikit-learn makes): LML, gradient and alpha."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    rng = np.random.default_rng(2000)
+    B, n = 5, 2000
+    xs, ys = _gp_tracks(rng, B, n)
+    xs[3], ys[3] = xs[3][:1937], ys[3][:1937]  # one track that does not fill its last tile
+    theta = np.tile(np.log([2.0, 60.0, 0.01]), (B, 1)) + rng.normal(0, 0.15, (B, 3))
+    batch = GpDeviceBatch(xs, ys)
+    lml, grad, status = batch.objective(theta)
+    assert not status.any()
+    alphas = batch.alpha()
+    for b in range(B):
+        l, g, _, a = gpo.lml_and_grad(theta[b], xs[b], ys[b])
+        assert np.isclose(lml[b], l, rtol=1e-9, atol=1e-7), (b, lml[b], l)
+        np.testing.assert_allclose(grad[b], g, rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(alphas[b], a, rtol=1e-6, atol=1e-6 * np.abs(a).max())
+
+
+@pytest.mark.timeout(900)
+def test_objective_at_config4_full_size_properties():
+    """BASELINE configs[4] at full size (1000 tracks x 2000 observations, 68 GB of matrices) through size-independent
+    properties: no status flags; a track gives the same bits wherever it sits in the batch (40 distinct tracks, 25
+    copies each, shuffled); a subset launch reproduces the full launch bit for bit; two tracks match the oracle."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    rng = np.random.default_rng(4)
+    nuniq, B, n = 40, 1000, 2000
+    uxs, uys = _gp_tracks(rng, nuniq, n)
+    utheta = np.tile(np.log([2.0, 60.0, 0.01]), (nuniq, 1)) + rng.normal(0, 0.15, (nuniq, 3))
+    idx = rng.permutation(np.arange(nuniq).repeat(B // nuniq))
+    batch = GpDeviceBatch([uxs[i] for i in idx], [uys[i] for i in idx])
+    theta = utheta[idx]
+    lml, grad, status = batch.objective(theta)
+    assert not status.any() and np.isfinite(lml).all() and np.isfinite(grad).all()
+    first = {}
+    for slot, src in enumerate(idx):
+        first.setdefault(int(src), slot)
+    ref_slot = np.array([first[int(src)] for src in idx])
+    assert np.array_equal(lml, lml[ref_slot]) and np.array_equal(grad, grad[ref_slot])
+    # subset launch: 37 scattered entries, after poisoning the outputs
+    sub = np.sort(rng.choice(B, 37, replace=False))
+    batch.t_lml.fill_(-7.0)
+    batch.t_grad.fill_(-7.0)
+    l2, g2, s2 = batch.objective(theta, active=sub.tolist())
+    assert np.array_equal(l2[sub], lml[sub]) and np.array_equal(g2[sub], grad[sub])
+    others = np.setdiff1d(np.arange(B), sub)
+    assert (l2[others] == -7.0).all()
+    for u in (0, 23):
+        l, g, _, _ = gpo.lml_and_grad(utheta[u], uxs[u], uys[u])
+        assert np.isclose(lml[first[u]], l, rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(grad[first[u]], g, rtol=1e-6, atol=1e-5)
+
+
+def test_fit_restarts_run_as_batch_entries():
+    """fit_thetas with restarts: all (restarts + 1) x B optimisers in one lock-step group give the optimum the one-at-a
+    -time loop over restarts finds (same starts, same objective bits), for a shared stream and for per-track streams;
+    an integer random_state in fit_batch means one stream per track, like a loop of single seeded fits."""
+    from sklearn.gaussian_process.kernels import RBF, WhiteKernel
+    from track_estimators.gaussian_processes import gaussian_process as gpm
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+    from track_estimators.ship_track import ShipTrack
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    tracks = []
+    for nme in NAMES:
+        st = ShipTrack()
+        st.dts, st.lon, st.lat = g[f"{nme}_dts"], g[f"{nme}_lon"], g[f"{nme}_lat"]
+        tracks.append(st)
+    kernel = 1.0 * RBF() + WhiteKernel(noise_level=0.5)
+    theta0, bounds = gpm._kernel_spec(kernel)
+    data = [gpm.GPRegression._training_data(st) for st in tracks]
+    batch = GpDeviceBatch([X[:, 0] for X, _ in data], [y for _, y in data])
+    grouped = gpm.fit_thetas(batch, theta0, bounds, 3, np.random.RandomState(5))
+    saved = gpm.MAX_LOCKSTEP_ENTRIES
+    try:
+        gpm.MAX_LOCKSTEP_ENTRIES = 1  # forces one restart per group: the sequential loop
+        serial = gpm.fit_thetas(batch, theta0, bounds, 3, np.random.RandomState(5))
+    finally:
+        gpm.MAX_LOCKSTEP_ENTRIES = saved
+    np.testing.assert_allclose(grouped[1], serial[1], rtol=1e-12)
+    np.testing.assert_allclose(grouped[0], serial[0], rtol=1e-9, atol=1e-9)
+    gp = gpm.GPRegression(kernel=kernel)
+    thetas, lml = gp.fit_batch(tracks, gpr_kwargs={"n_restarts_optimizer": 2, "random_state": 0})
+    for b in range(len(tracks)):
+        m = gpm.GPRegression(kernel=kernel).fit(tracks[b], gpr_kwargs={"n_restarts_optimizer": 2, "random_state": 0})
+        assert np.isclose(lml[b], m.log_marginal_likelihood_value_, rtol=1e-10)
+        np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-8, atol=1e-8)

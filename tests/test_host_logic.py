@@ -139,3 +139,29 @@ def test_synthetic_tracks_are_batch_independent():
     b = synthetic.make_batch(3, nobs=9, seed0=103)
     assert np.array_equal(a.z[3:], b.z) and np.array_equal(a.sog_rate[3:], b.sog_rate)
     assert np.abs(a.lat).max() < 80
+
+
+def test_host_shiptrack_sphere_vs_reference_shiptrack():
+    """The package's host ShipTrack against sog / cog / rates / z produced by RUNNING the reference's ShipTrack with its
+    sphere pair on 42 ragged tracks incl. duplicate timestamps and the 0/360 seam (tests/golden/track_prep.npz): exact,
+    NaN / inf in the same places."""
+    import os
+
+    from conftest import GOLDEN
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import haversine_formula, heading
+
+    g = np.load(os.path.join(GOLDEN, "track_prep.npz"))
+    for b in range(len(g["nobs"])):
+        T = int(g["nobs"][b])
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.lon, st.lat, st.dts = g["lon"][b, :T].copy(), g["lat"][b, :T].copy(), g["dts"][b, : T - 1].copy()
+        with np.errstate(all="ignore"):
+            st.calculate_cog()
+            st.calculate_sog()
+            st.calculate_sog_rate()
+            st.calculate_cog_rate()
+            z = st.get_measurements(include_sog=True, include_cog=True)
+        for k in ("sog", "cog", "sog_rate", "cog_rate"):
+            np.testing.assert_array_equal(getattr(st, k), g[k][b, :T], err_msg=k)
+        np.testing.assert_array_equal(z, g["z"][b, :, :T])
