@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2_pmc2
+O=$R/gpurun_out/${PMC_OUT:-r2_pmc3}
 mkdir -p $O
 cd $R
 python -m pytest tests/test_pipeline.py -m gpu -x -q > $O/pytest_pipeline.log 2>&1 || exit 1

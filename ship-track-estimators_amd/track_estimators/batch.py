@@ -413,13 +413,14 @@ class SmootherPipeline:
     """
     Forward passes and smoothers of consecutive batches on disjoint parts of the GPU, several in flight.
 
-    A batch of BASELINE size (10 000 tracks) is 625 long-running forward waves on 1 024 SIMDs followed by a
-    latency-bound smoother.  Run back to back they leave most of the chip idle; run side by side on ordinary streams
+    A batch of BASELINE size (10 000 tracks) is a few hundred long-running forward waves on 1 024 SIMDs followed by a
+    memory-bound smoother.  Run back to back they leave most of the chip idle; run side by side on ordinary streams
     they land on the same SIMDs and take each other's issue slots.  Here forward passes run on streams restricted to
     the first ``forward_cus`` compute units and smoothers on streams restricted to the rest
-    (``ste_stream_create_cu_range``).  The forward kernel needs at most 256 VGPRs, so forward passes share the forward
-    partition with two waves per SIMD -- a lone wave can use only half of the fp64 pipe's issue slots -- and the
-    smoothers of two batches share the smoother partition, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
+    (``ste_stream_create_cu_range``).  By default the forward passes run with one lane per track (``forward_lanes``):
+    157 waves per 10 000-track batch, half the instructions per track of the quad mapping that is best for a batch on
+    its own, and five of them in flight fill the 640 SIMDs of a 160-CU partition; the smoothers of two batches share
+    the other 96 CUs, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
     its histories and work rows; a batch is not resubmitted before its previous smoother has finished (events), so the
     caller rotates through ``buffers_needed`` or more of them.
 
@@ -434,24 +435,31 @@ class SmootherPipeline:
     """
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
-                 forward_streams: Optional[int] = None, smoother_streams: int = 2):
+                 forward_streams: Optional[int] = None, smoother_streams: int = 2, forward_lanes: int = 1):
         import torch
 
         self.torch = torch
         self.lib = binding.require_gpu()
         self.device = torch.device(device)
+        if forward_lanes not in (0, 1, 4):
+            raise ValueError(f"forward_lanes must be 0 (the library's choice by batch size), 1 or 4, got {forward_lanes!r}")
+        self.forward_lanes = int(forward_lanes)
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        quad = forward_lanes == 4 or (forward_lanes == 0 and (ntracks or 10_000) <= 32_768)
         if forward_cus is None:
-            # Three quarters of the chip for the forward passes (192 of 256 CUs, 24 per XCD).  The smoother moves ~500 B
-            # per track-step at ~28 GB/s per CU whatever the partition size, ~90 CU-ms per 10 000 x 500 batch, against
-            # ~280 CU-ms of forward pass; below a quarter of the chip its workgroups (two per CU) no longer fit in one
-            # round and it becomes the bottleneck (measured: 1.57 ms per step at 192 + 64, 2.3 ms at 200 + 56).
-            forward_cus = (ncu * 3 // 4) // 8 * 8
+            # The smoother moves ~450 B per track-step at ~28 GB/s per CU whatever the partition size (~90 CU-ms per
+            # 10 000 x 500 batch) and needs its workgroups (two per CU) in one round.  A lane-per-track forward pass costs
+            # ~160 CU-ms, a quad-per-track one ~280: five eighths of the chip for the former (160 + 96 CUs: 1.17 ms per
+            # step at 10 000 tracks; 144 + 112: 1.34, 168 + 88: 1.45), three quarters for the latter (192 + 64: 1.49).
+            forward_cus = (ncu * (3 if quad else 5) // (4 if quad else 8)) // 8 * 8
         if forward_streams is None:
-            # as many forward passes in flight as fill the partition's wave slots (two per SIMD: the kernel holds 256
-            # VGPRs), rounded up -- the waves of the last pass start as slots come free -- and at most three
-            waves = -(-(ntracks or 10_000) * 4 // 64)
-            forward_streams = max(1, min(3, -(-forward_cus * 8 // waves)))
+            # as many forward passes in flight as fill the partition's wave slots, rounded up (the waves of the last pass
+            # start as slots come free): a lane-per-track wave holds a SIMD's whole register file, quad-per-track waves
+            # (256 VGPRs) fit two to a SIMD
+            nt = ntracks or 10_000
+            waves = -(-nt * 4 // 64) if quad else -(-nt // 64)
+            slots = forward_cus * (8 if quad else 4)
+            forward_streams = max(1, min(3 if quad else 6, -(-slots // waves)))
         if not (0 < forward_cus < ncu):
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
@@ -518,7 +526,16 @@ class SmootherPipeline:
             fwd_stream.wait_stream(torch.cuda.current_stream(self.device))  # uploads queued by the constructor
         if timing is not None:
             timing[0].record(fwd_stream)
-        db.forward(fwd_stream)
+        # Lane mapping of the forward pass: with several passes sharing the partition a lane per track is the better
+        # shape even for small batches -- half the instructions per track of the quad mapping, and the other passes'
+        # waves fill the SIMDs a 157-wave pass leaves empty.  A mapping named by the batch itself (HostBatch.lanes) wins.
+        flags = db.struct.flags
+        if self.forward_lanes and not (flags & (binding.STE_FLAG_LANES_1 | binding.STE_FLAG_LANES_4)):
+            db.struct.flags = flags | (binding.STE_FLAG_LANES_1 if self.forward_lanes == 1 else binding.STE_FLAG_LANES_4)
+        try:
+            db.forward(fwd_stream)
+        finally:
+            db.struct.flags = flags
         ready = timing[1] if timing is not None else torch.cuda.Event()
         ready.record(fwd_stream)
         bwd_stream.wait_event(ready)

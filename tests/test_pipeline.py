@@ -20,6 +20,7 @@ def test_pipeline_matches_serial_runs():
     hbs = [_batch(300, 0), _batch(300, 1000), _batch(300, 2000)]
     want = []
     for hb in hbs:
+        hb.lanes = 1  # the pipeline's forward passes run with one lane per track; same mapping, same bits
         db = batch.DeviceBatch(hb)
         db.run()
         torch.cuda.synchronize()
@@ -75,11 +76,18 @@ def test_pipeline_full_size_matches_serial():
     H, Q, R, P0 = synthetic.example_matrices()
     sb = synthetic.make_batch(10_000, nobs=126, gap_h=1.0, seed0=31)
     hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    quad = batch.DeviceBatch(hb)  # a batch on its own: the library picks the quad mapping at this size
+    quad.run()
+    hb.lanes = 1
     ref = batch.DeviceBatch(hb)
     ref.run()
     torch.cuda.synchronize()
+    hb.lanes = None
+    err = (quad.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
+    assert float(err.max()) < 1e-7  # the two lane mappings round differently, nothing more (tolerance: 1e-6)
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert pipe.forward_cus + pipe.smoother_cus == 256 and pipe.buffers_needed == len(pipe.fwd_streams) + len(pipe.bwd_streams) + 1
+    assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 5, 2)
+    assert pipe.buffers_needed == 8
     dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
     for k in range(8):
         pipe.submit(dbs[k % 3], final=(k == 7))
@@ -93,7 +101,7 @@ def test_pipeline_full_size_matches_serial():
 
 def test_pipeline_config2_shard_size():
     """BASELINE.json configs[2]'s shard (100 000 tracks / 8 GPUs = 12 500 tracks x 500 steps) through the default
-    pipeline for that size: the partition is the measured one (192 + 64 CUs, two forward passes in flight), seven
+    pipeline for that size: the partition is the measured one (160 + 96 CUs, four lane-per-track forward passes in flight), seven
     pipelined steps leave exactly the bits of a batch run on its own, and a sample of tracks matches the oracle."""
     import torch
     from oracle import ukf_oracle as orc
@@ -101,11 +109,13 @@ def test_pipeline_config2_shard_size():
     H, Q, R, P0 = synthetic.example_matrices()
     sb = synthetic.make_batch(12_500, nobs=126, gap_h=1.0, seed0=87_500)  # the last shard of the 100 000-track job
     hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    hb.lanes = 1
     ref = batch.DeviceBatch(hb)
     ref.run()
     torch.cuda.synchronize()
+    hb.lanes = None
     with batch.SmootherPipeline("cuda:0", ntracks=hb.B) as pipe:
-        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (192, 64, 2, 2)
+        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 4, 2)
         dbs = [batch.DeviceBatch(hb) for _ in range(pipe.buffers_needed)]
         for k in range(7):
             pipe.submit(dbs[k % len(dbs)], final=(k == 6))
