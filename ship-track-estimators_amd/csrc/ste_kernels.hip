@@ -283,15 +283,11 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
                                            double cr, const double* noise, size_t nrow, size_t B, size_t t,
                                            const double* noise_rts, double* work, EigBasis& fan_basis,
                                            EigBasis& pb_basis) {
-    double sig[9][4], dev0[9][4];
-    int st = propagate_fan<kWarm>(x, P, p.fan_scale, dt, sr, cr, dev0, sig, fan_basis);
-    if (kGains) {
-        STE_UNROLL
-        for (int j = 0; j < 9; ++j) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) dev0[j][c] -= x[c];  // S_orig of unscented.py:329
-        }
-    }
+    (void)pb_basis;
+    double sig[9][4], sig0[9][4], T[4][4];
+    int st = sym_sqrt4<kWarm>(P, p.fan_scale, T, fan_basis);
+    if (kWarm) fan_basis.valid = true;
+    propagate_points(x, T, dt, sr, cr, sig0, sig);
     double m[4];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
@@ -300,33 +296,57 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         for (int j = 1; j < 9; ++j) acc += sig[j][c];
         m[c] = fma(p.w0, sig[0][c], p.wi * acc);
     }
-    if (kGains && work) {
-        double xb[4], dk[9][4], db[9][4];
+    double xp[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xp[c] = m[c];
+    if (noise) {
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) xb[c] = m[c];
+        for (int c = 0; c < 4; ++c) xp[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    // the two columns of the cross-covariance the smoother needs (see kWorkD), while the points are still whole:
+    // chi_0 - x_k = 0 and chi_{i+-} - x_k = +-T_i, so D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T and x_b cancels
+    double D2[4][2];
+    if (kGains && work) {
+        STE_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            double dl[4];
+            STE_UNROLL
+            for (int i = 0; i < 4; ++i) dl[i] = sig[1 + i][c] - sig[5 + i][c];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                double acc = T[r][0] * dl[0];
+                STE_UNROLL
+                for (int i = 1; i < 4; ++i) acc = fma(T[r][i], dl[i], acc);
+                D2[r][c] = p.wi * acc;
+            }
+        }
+    }
+    STE_UNROLL
+    for (int j = 0; j < 9; ++j) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) sig[j][c] -= xp[c];
+    }
+    double Pn[4][4];
+    weighted_outer<true>(sig, sig, p.w0, p.wi, Pn);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) Pn[r][c] += p.Q[r * 4 + c];
+    }
+    if (kGains && work) {
+        // P_b is centred on the filtered mean x_k, not on the predicted one (unscented.py:324-325).  With b = x^- - x_k
+        // and e = (weighted mean) - x^- (minus the injected predict noise) and weights that sum to one,
+        //   P_b = sum W (chi' - x_k)(chi' - x_k)^T + Q = P^- + e b^T + b e^T + b b^T.
+        double xb[4], bv[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            xb[c] = m[c];
+            bv[c] = xp[c] - x[c];
+        }
         if (noise_rts) {
             STE_UNROLL
             for (int c = 0; c < 4; ++c) xb[c] += noise_rts[(nrow * 4 + c) * B + t];
         }
-        STE_UNROLL
-        for (int j = 0; j < 9; ++j) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) {
-                dk[j][c] = sig[j][c] - x[c];
-                db[j][c] = sig[j][c] - xb[c];
-            }
-        }
-        // The gain K = D pinv(P_b) is NOT on the forward recursion's critical path: P_b and D are stored and a fully
-        // smoother's producer waves (urtss_smooth_wg) turn D into K afterwards.
-        double Pb[4][4], D[4][4];
-        weighted_outer<true>(dk, dk, p.w0, p.wi, Pb);
-        STE_UNROLL
-        for (int r = 0; r < 4; ++r) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) Pb[r][c] += p.Q[r * 4 + c];
-        }
-        weighted_outer<false>(dev0, db, p.w0, p.wi, D);
-        (void)pb_basis;
         double* w = work + (nrow * kWorkElems) * B + t;
         STE_UNROLL
         for (int c = 0; c < 4; ++c) w[(kWorkXb + c) * B] = xb[c];
@@ -334,30 +354,23 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = r; c < 4; ++c) w[(e++) * B] = Pb[r][c];
+            for (int c = r; c < 4; ++c) {
+                double v = fma(bv[r], bv[c], Pn[r][c]);
+                if (noise) v += fma(m[r] - xp[r], bv[c], bv[r] * (m[c] - xp[c]));
+                w[(e++) * B] = v;
+            }
         }
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = 0; c < 2; ++c) w[(kWorkD + r * 2 + c) * B] = D[r][c];
+            for (int c = 0; c < 2; ++c) w[(kWorkD + r * 2 + c) * B] = D2[r][c];
         }
     }
     STE_UNROLL
-    for (int c = 0; c < 4; ++c) x[c] = m[c];
-    if (noise) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) x[c] += noise[(nrow * 4 + c) * B + t];
-    }
-    STE_UNROLL
-    for (int j = 0; j < 9; ++j) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) sig[j][c] -= x[c];
-    }
-    weighted_outer<true>(sig, sig, p.w0, p.wi, P);
-    STE_UNROLL
     for (int r = 0; r < 4; ++r) {
+        x[r] = xp[r];
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) P[r][c] += p.Q[r * 4 + c];
+        for (int c = 0; c < 4; ++c) P[r][c] = Pn[r][c];
     }
     return st;
 }
