@@ -458,7 +458,21 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
         STE_UNROLL
         for (int c = 0; c < 4; ++c) S[r][c] += R[r][c];
     }
-    const int st = sym_pinv4(S, Si) | rst;
+    int st = rst;
+    {
+        bool blk = true;  // S confined to its leading 2 x 2 block (exact zeros elsewhere), for every track of the wave
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                if (r >= 2 || c >= 2) blk = blk && (S[r][c] == 0.0);
+            }
+        }
+        if (__all(blk))
+            sym_pinv4_block2(S, Si);
+        else
+            st |= sym_pinv4(S, Si);
+    }
     mmt(P, H, PHt);
     mm(PHt, Si, K);
     double y[4];

@@ -546,7 +546,8 @@ __device__ __forceinline__ int sym_sqrt4(const double (&P)[4][4], double scale, 
     STE_UNROLL
     for (int i = 0; i < 4; ++i) {
         if (w[i] < -1e-12 * wmax) st |= 0x2;
-        f[i] = sqrt(fmax(w[i], 0.0));
+        // sqrt(max(w, 0)) as w * rsqrt(w): a third of the instructions of the correctly rounded sqrt sequence, ~1 ulp
+        f[i] = w[i] > 0.0 ? w[i] * rsqrt_fast(w[i]) : 0.0;
     }
     recompose(V, f, T);
     return st;
@@ -588,6 +589,34 @@ __device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4
 __device__ __forceinline__ int sym_pinv4(const double (&S)[4][4], double (&Si)[4][4]) {
     EigBasis none;
     return sym_pinv4<false>(S, Si, none);
+}
+
+// The same for an S that is zero outside its leading 2 x 2 block -- S = H P H^T + R with an H that observes two components
+// (the reference's H = diag(1, 1, 0, 0)): its eigen-decomposition is ONE exact rotation, with the formulas of jacobi_rot,
+// instead of sweeps over a matrix that is three quarters zeros.  The caller checks the structure (wave-uniformly).
+__device__ __forceinline__ void sym_pinv4_block2(const double (&S)[4][4], double (&Si)[4][4]) {
+    const double a = S[0][0], d = S[1][1], b = 0.5 * (S[0][1] + S[1][0]);
+    const bool go = b * b > kRotTol2 * fabs(a * d);
+    const double delta = d - a, two_b = b + b;
+    const double rh = rsqrt_fast(go ? fma(delta, delta, two_b * two_b) : 1.0);
+    const double c2 = fma(0.5 * fabs(delta), rh, 0.5);
+    const double rc = rsqrt_fast(c2);
+    const double c = go ? c2 * rc : 1.0;
+    const double sn = go ? (delta < 0.0 ? -b : b) * rh * rc : 0.0;
+    const double tb = go ? sn * rc * b : 0.0;
+    const double w0 = a - tb, w1 = d + tb;
+    const double cutoff = kPinvRcond * fmax(fabs(w0), fabs(w1));
+    const double f0 = (fabs(w0) > cutoff) ? 1.0 / w0 : 0.0, f1 = (fabs(w1) > cutoff) ? 1.0 / w1 : 0.0;
+    const double cc = c * c, ss = sn * sn, cs = c * sn;  // pinv = V diag(f) V^T with V = [[c, s], [-s, c]]
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int q = 0; q < 4; ++q) Si[r][q] = 0.0;
+    }
+    Si[0][0] = fma(cc, f0, ss * f1);
+    Si[1][1] = fma(ss, f0, cc * f1);
+    Si[0][1] = cs * (f1 - f0);
+    Si[1][0] = Si[0][1];
 }
 
 // 1/d for normal d of either sign: v_rcp_f64 (~2^-24) and two Newton steps (below 2^-80 before the final rounding).
