@@ -482,6 +482,27 @@ def example_cases():
     return out
 
 
+def smooth_case():
+    """SOG / COG pre-smoothing as the reference CLI does it (cli/main_cli.py:99-109 with utils.smooth, utils.py:150-172):
+    calculate_cog / calculate_sog, moving average of width 5, then get_measurements(True, True) and the rates -- on ship
+    01203823 of the reference's CLI example, sphere pair injected."""
+    from track_estimators.utils import smooth
+
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv("/root/reference/data/historical_ships/historical_ship_data.csv", ship_id="01203823", id_col="primary.id",
+                lat_col="lat", lon_col="lon")
+    st.calculate_cog()
+    st.calculate_sog()
+    raw_sog, raw_cog = st.sog.copy(), st.cog.copy()
+    st.sog = smooth(st.sog, 5)
+    st.cog = smooth(st.cog, 5)
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    return dict(box=np.int64(5), raw_sog=raw_sog, raw_cog=raw_cog, sog=st.sog, cog=st.cog, z=z, sog_rate=st.sog_rate,
+                cog_rate=st.cog_rate, smooth_even=smooth(np.arange(7.0) ** 2, 4))
+
+
 def two_runs_case():
     """A second ``run`` on the same filter object appends to the history and keeps the running time
     (kalman_filter.py:22-31,98): the update index restarts at 0 while ``self.time`` continues, so the float-equality
@@ -652,13 +673,15 @@ def main():
     np.savez_compressed(os.path.join(HERE, "modern_ships_robust.npz"), **modern_robust_cases())
     np.savez_compressed(os.path.join(HERE, "track_prep.npz"), **prep_cases())
     np.savez_compressed(os.path.join(HERE, "batch_examples.npz"), **example_cases())
+    np.savez_compressed(os.path.join(HERE, "cli_smooth.npz"), **smooth_case())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
 SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
-              "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz")}
+              "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz"),
+              "smooth": (smooth_case, "cli_smooth.npz")}
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py robust prep ...

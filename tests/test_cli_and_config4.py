@@ -94,6 +94,54 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_cli_with_presmoothing(tmp_path, monkeypatch, capsys):
+    """input.json key `smooth` (reference cli/main_cli.py:99-104, :209-212): SOG / COG are moving-averaged before the
+    measurements and rates are formed.  The host arithmetic of that step is pinned to the reference in
+    tests/test_host_logic.py::test_cli_presmoothing_vs_reference; here the CLI plumbing: the log line, a different prior
+    speed / course in row 0 than without smoothing, and equality with the class API fed the same smoothed track."""
+    from track_estimators.cli.main_cli import track_estimator
+    from track_estimators.kalman_filters.non_linear_process import geodetic_dynamics
+    from track_estimators.kalman_filters.unscented import UnscentedKalmanFilter
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import generate_dts, smooth
+
+    monkeypatch.chdir(tmp_path)
+    base = {"dim": 4, "H": [1, 1, 0, 0], "R": [0.001, 0.001, 0, 0], "Q": [1e-2, 1e-2, 1e-4, 1e-4], "P": [1.0, 1.0, 1.0, 1.0],
+            "dt": -1, "nsteps": 2}
+    csv = os.path.join(GOLDEN, "ship_01203823.csv")
+    with open("input.json", "w") as f:
+        json.dump(dict(base, smooth=5), f)
+    track_estimator(["-i", "input.json", "-o", "sm5", "-t", csv, "-s", "01203823", "-ic", "primary.id", "-lat", "lat", "-lon", "lon",
+                     "-rts", "--no-noise"])
+    assert "Smoothing SOG and COG by 5." in capsys.readouterr().out
+    pred = np.loadtxt("sm5_01203823_predictions.txt")
+    smo = np.loadtxt("sm5_01203823_predictions_smoothed.txt")
+    assert pred.shape == (103, 4) and smo.shape == (103, 4) and np.all(np.isfinite(smo))
+    assert abs(pred[0, 2] - 14.578418614021368) > 1e-3  # the prior's speed is the smoothed one
+    st = ShipTrack()
+    st.read_csv(csv, ship_id="01203823", id_col="primary.id")
+    st.calculate_cog()
+    st.calculate_sog()
+    st.sog, st.cog = smooth(st.sog, 5), smooth(st.cog, 5)
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    H, R, Q, P = (np.diag(base[k]).astype(float) for k in ("H", "R", "Q", "P"))
+    ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=z[:, 0].reshape(-1, 1).copy(), non_linear_process=geodetic_dynamics)
+    ukf.inject_noise = False
+    dt = generate_dts(st.dts, 2)
+    m, _ = ukf.run(len(dt), dt, st)
+    np.testing.assert_allclose(pred, m, rtol=1e-12, atol=1e-12)
+    with open("input.json", "w") as f:
+        json.dump(dict(base, smooth=1), f)  # -1, 0, 1 and a missing key all mean "no smoothing"
+    track_estimator(["-i", "input.json", "-o", "sm1", "-t", csv, "-s", "01203823", "-ic", "primary.id", "-lat", "lat", "-lon", "lon",
+                     "--no-noise"])
+    assert "Smoothing" not in capsys.readouterr().out
+    np.testing.assert_allclose(np.loadtxt("sm1_01203823_predictions.txt")[0], [-30.5, -0.5, 14.578418614021368, 198.52495095065817],
+                               rtol=1e-11)
+
+
+@pytest.mark.gpu
 def test_robust_helpers_and_flag():
     """criterion_index / update_lambda_factor methods vs the reference's known answers; the opt-in robust update of the
     batched path vs the oracle's restatement of check_robustness (noise-free)."""

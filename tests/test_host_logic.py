@@ -165,3 +165,29 @@ def test_host_shiptrack_sphere_vs_reference_shiptrack():
         for k in ("sog", "cog", "sog_rate", "cog_rate"):
             np.testing.assert_array_equal(getattr(st, k), g[k][b, :T], err_msg=k)
         np.testing.assert_array_equal(z, g["z"][b, :, :T])
+
+
+def test_cli_presmoothing_vs_reference():
+    """SOG / COG pre-smoothing (reference cli/main_cli.py:99-109): calculate, moving-average with utils.smooth, then
+    get_measurements and the rates -- against arrays produced by the reference on its CLI example's ship."""
+    import os
+
+    from conftest import GOLDEN
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import haversine_formula, heading, smooth
+
+    g = np.load(os.path.join(GOLDEN, "cli_smooth.npz"))
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv(os.path.join(GOLDEN, "ship_01203823.csv"), ship_id="01203823", id_col="primary.id", lat_col="lat", lon_col="lon")
+    st.calculate_cog()
+    st.calculate_sog()
+    assert np.array_equal(st.sog, g["raw_sog"]) and np.array_equal(st.cog, g["raw_cog"])
+    st.sog = smooth(st.sog, int(g["box"]))
+    st.cog = smooth(st.cog, int(g["box"]))
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    for k in ("sog", "cog", "sog_rate", "cog_rate"):
+        np.testing.assert_array_equal(getattr(st, k), g[k], err_msg=k)
+    np.testing.assert_array_equal(z, g["z"])
+    np.testing.assert_array_equal(smooth(np.arange(7.0) ** 2, 4), g["smooth_even"])
