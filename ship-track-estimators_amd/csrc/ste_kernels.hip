@@ -70,11 +70,13 @@ __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t 
         for (int c = 0; c < 4; ++c) M[r][c] = base[(row * 16 + r * 4 + c) * B + t];
     }
 }
+// (nontemporal stores for the histories and work rows were measured: no change, 1.013 vs 1.011 ms per pipelined step)
+__device__ __forceinline__ void st_stream(double* p, double v) { *p = v; }
 __device__ __forceinline__ void store_mat(double* base, size_t row, size_t B, size_t t, const double (&M)[4][4]) {
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) base[(row * 16 + r * 4 + c) * B + t] = M[r][c];
+        for (int c = 0; c < 4; ++c) st_stream(&base[(row * 16 + r * 4 + c) * B + t], M[r][c]);
     }
 }
 __device__ __forceinline__ void load_vec(const double* base, size_t row, size_t B, size_t t, double (&v)[4]) {
@@ -83,7 +85,7 @@ __device__ __forceinline__ void load_vec(const double* base, size_t row, size_t 
 }
 __device__ __forceinline__ void store_vec(double* base, size_t row, size_t B, size_t t, const double (&v)[4]) {
     STE_UNROLL
-    for (int c = 0; c < 4; ++c) base[(row * 4 + c) * B + t] = v[c];
+    for (int c = 0; c < 4; ++c) st_stream(&base[(row * 4 + c) * B + t], v[c]);
 }
 
 __device__ __forceinline__ bool all_finite(const double (&x)[4], const double (&P)[4][4]) {
@@ -134,7 +136,7 @@ __device__ __forceinline__ int sigma_fan(const double (&x)[4], const double (&P)
 // The 2n points come in +- pairs around the centre, so their angles are (centre angle) +- (small increment) and
 // sin/cos of all of them follow from the centre's three sincos and one sincos per increment by the angle-addition
 // formulas: 15 sincos evaluations instead of 27, 12 of them on small arguments that need no range reduction.
-__device__ __forceinline__ void propagate_fan_branching(const double (&x)[4], const double (&T)[4][4], double dt, double sr,
+__device__ __noinline__ void propagate_fan_branching(const double (&x)[4], const double (&T)[4][4], double dt, double sr,
                                                         double cr, double (&sig0)[9][4], double (&sig)[9][4]) {
     const double dt_r = dt / kEarthRadius;
     const double du = sr * dt, da = cr * dt;
@@ -237,7 +239,27 @@ __device__ __forceinline__ void propagate_points(const double (&x)[4], const dou
         sig[5 + i][2] = ptm[2] + du;
         sig[5 + i][3] = fma(ptm[3] * kDeg2Rad, kRad2Deg, da);
     }
-    if (__builtin_expect(__any(!ok), 0)) propagate_fan_branching(x, T, dt, sr, cr, sig0, sig);
+    if (__builtin_expect(__any(!ok), 0)) {
+        // Out of line, through copies: the branching version calls the device library (Payne-Hanek sincos, atan2, asin) and
+        // is ~55 KB of code; inlined it tripled this kernel's size and register pressure.  Its arguments are address-taken,
+        // so they are private copies here and the hot path's arrays stay in registers.
+        double xc[4], Tc[4][4], s0c[9][4], sc[9][4];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            xc[r] = x[r];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Tc[r][c] = T[r][c];
+        }
+        propagate_fan_branching(xc, Tc, dt, sr, cr, s0c, sc);
+        STE_UNROLL
+        for (int j = 0; j < 9; ++j) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                sig0[j][c] = s0c[j][c];
+                sig[j][c] = sc[j][c];
+            }
+        }
+    }
 }
 
 
@@ -349,7 +371,7 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
         }
         double* w = work + (nrow * kWorkElems) * B + t;
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) w[(kWorkXb + c) * B] = xb[c];
+        for (int c = 0; c < 4; ++c) st_stream(&w[(kWorkXb + c) * B], xb[c]);
         int e = kWorkPb;
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
@@ -357,13 +379,13 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
             for (int c = r; c < 4; ++c) {
                 double v = fma(bv[r], bv[c], Pn[r][c]);
                 if (noise) v += fma(m[r] - xp[r], bv[c], bv[r] * (m[c] - xp[c]));
-                w[(e++) * B] = v;
+                st_stream(&w[(e++) * B], v);
             }
         }
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = 0; c < 2; ++c) w[(kWorkD + r * 2 + c) * B] = D2[r][c];
+            for (int c = 0; c < 2; ++c) st_stream(&w[(kWorkD + r * 2 + c) * B], D2[r][c]);
         }
     }
     STE_UNROLL
