@@ -94,7 +94,7 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_cli_with_presmoothing(tmp_path, monkeypatch, capsys):
+def test_cli_with_presmoothing(tmp_path, monkeypatch, caplog):
     """input.json key `smooth` (reference cli/main_cli.py:99-104, :209-212): SOG / COG are moving-averaged before the
     measurements and rates are formed.  The host arithmetic of that step is pinned to the reference in
     tests/test_host_logic.py::test_cli_presmoothing_vs_reference; here the CLI plumbing: the log line, a different prior
@@ -105,6 +105,9 @@ def test_cli_with_presmoothing(tmp_path, monkeypatch, capsys):
     from track_estimators.ship_track import ShipTrack
     from track_estimators.utils import generate_dts, smooth
 
+    import logging
+
+    caplog.set_level(logging.INFO)
     monkeypatch.chdir(tmp_path)
     base = {"dim": 4, "H": [1, 1, 0, 0], "R": [0.001, 0.001, 0, 0], "Q": [1e-2, 1e-2, 1e-4, 1e-4], "P": [1.0, 1.0, 1.0, 1.0],
             "dt": -1, "nsteps": 2}
@@ -113,7 +116,7 @@ def test_cli_with_presmoothing(tmp_path, monkeypatch, capsys):
         json.dump(dict(base, smooth=5), f)
     track_estimator(["-i", "input.json", "-o", "sm5", "-t", csv, "-s", "01203823", "-ic", "primary.id", "-lat", "lat", "-lon", "lon",
                      "-rts", "--no-noise"])
-    assert "Smoothing SOG and COG by 5." in capsys.readouterr().out
+    assert "Smoothing SOG and COG by 5." in caplog.text
     pred = np.loadtxt("sm5_01203823_predictions.txt")
     smo = np.loadtxt("sm5_01203823_predictions_smoothed.txt")
     assert pred.shape == (103, 4) and smo.shape == (103, 4) and np.all(np.isfinite(smo))
@@ -132,11 +135,12 @@ def test_cli_with_presmoothing(tmp_path, monkeypatch, capsys):
     dt = generate_dts(st.dts, 2)
     m, _ = ukf.run(len(dt), dt, st)
     np.testing.assert_allclose(pred, m, rtol=1e-12, atol=1e-12)
+    caplog.clear()
     with open("input.json", "w") as f:
         json.dump(dict(base, smooth=1), f)  # -1, 0, 1 and a missing key all mean "no smoothing"
     track_estimator(["-i", "input.json", "-o", "sm1", "-t", csv, "-s", "01203823", "-ic", "primary.id", "-lat", "lat", "-lon", "lon",
                      "--no-noise"])
-    assert "Smoothing" not in capsys.readouterr().out
+    assert "Smoothing" not in caplog.text
     np.testing.assert_allclose(np.loadtxt("sm1_01203823_predictions.txt")[0], [-30.5, -0.5, 14.578418614021368, 198.52495095065817],
                                rtol=1e-11)
 
