@@ -453,13 +453,15 @@ class SmootherPipeline:
             # step at 10 000 tracks; 144 + 112: 1.34, 168 + 88: 1.45), three quarters for the latter (192 + 64: 1.49).
             forward_cus = (ncu * (3 if quad else 5) // (4 if quad else 8)) // 8 * 8
         if forward_streams is None:
-            # as many forward passes in flight as fill the partition's wave slots, rounded up (the waves of the last pass
-            # start as slots come free): a lane-per-track wave holds a SIMD's whole register file, quad-per-track waves
-            # (256 VGPRs) fit two to a SIMD
+            # as many forward passes in flight as fill the partition's wave slots: a lane-per-track wave holds a SIMD's
+            # whole register file, quad-per-track waves (256 VGPRs) fit two to a SIMD.  Quad passes: rounded up (the waves
+            # of the last pass start as slots come free: 3 on 192 CUs beat 2).  Lane-per-track passes: rounded to nearest
+            # (10 000 tracks on 160 CUs: 4.08 -> 4, 1.02 ms per step with 4 or 5; 12 500 tracks: 3.27 -> 3, 1.53 ms
+            # against 1.68 with 4).
             nt = ntracks or 10_000
             waves = -(-nt * 4 // 64) if quad else -(-nt // 64)
             slots = forward_cus * (8 if quad else 4)
-            forward_streams = max(1, min(3 if quad else 6, -(-slots // waves)))
+            forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(6, (2 * slots + waves) // (2 * waves)))
         if not (0 < forward_cus < ncu):
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:

@@ -86,8 +86,8 @@ def test_pipeline_full_size_matches_serial():
     err = (quad.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
     assert float(err.max()) < 1e-7  # the two lane mappings round differently, nothing more (tolerance: 1e-6)
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 5, 2)
-    assert pipe.buffers_needed == 8
+    assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 4, 2)
+    assert pipe.buffers_needed == 7
     dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
     for k in range(8):
         pipe.submit(dbs[k % 3], final=(k == 7))
@@ -101,7 +101,7 @@ def test_pipeline_full_size_matches_serial():
 
 def test_pipeline_config2_shard_size():
     """BASELINE.json configs[2]'s shard (100 000 tracks / 8 GPUs = 12 500 tracks x 500 steps) through the default
-    pipeline for that size: the partition is the measured one (160 + 96 CUs, four lane-per-track forward passes in flight), seven
+    pipeline for that size: the partition is the measured one (160 + 96 CUs, three lane-per-track forward passes in flight), seven
     pipelined steps leave exactly the bits of a batch run on its own, and a sample of tracks matches the oracle."""
     import torch
     from oracle import ukf_oracle as orc
@@ -115,7 +115,7 @@ def test_pipeline_config2_shard_size():
     torch.cuda.synchronize()
     hb.lanes = None
     with batch.SmootherPipeline("cuda:0", ntracks=hb.B) as pipe:
-        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 4, 2)
+        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 3, 2)
         dbs = [batch.DeviceBatch(hb) for _ in range(pipe.buffers_needed)]
         for k in range(7):
             pipe.submit(dbs[k % len(dbs)], final=(k == 6))
