@@ -135,8 +135,8 @@ def main():
 def _main(stack):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--total-tracks", type=int, default=None,
                     help="tracks of the whole job, cut into one contiguous shard per GPU (default: 10 000 at --gpus 1 = "
                          "BASELINE configs[1]; 12 500 x N otherwise = configs[2]'s shard size, 100 000 at --gpus 8)")
