@@ -130,8 +130,9 @@ typedef struct ste_ukf_batch_f64 {
      * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) on the fly and runs the
      * recurrence (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Tracks
      * whose forward status carries CLAMPED or NOCONV (the identity for D's last columns needs an exact square root) are
-     * smoothed by the stand-alone kernel in the same call.  Results are those of the stand-alone smoother to rounding.  NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history
-     * was not produced by ste_ukf_forward_f64 on this batch).
+     * smoothed by the stand-alone kernel in the same call.  Results are those of the stand-alone smoother to rounding.
+     * NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history was not
+     * produced by ste_ukf_forward_f64 on this batch).
      */
     double* rts_work;
 
