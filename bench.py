@@ -396,7 +396,7 @@ def _main(stack):
                                      "bytes_down": int(sum(res[k].nbytes for k in ("means", "covs", "means_smoothed",
                                                                                      "covs_smoothed")))}
             del res
-        if args.cpu_tracks > 0:
+        if args.cpu_tracks > 0 and world == 1:  # the CPU baseline is a rank-0, N = 1 leg
             v, secs, ref, chb = cpu_baseline(args.cpu_tracks)
             # the CPU sample is the first cpu_tracks tracks of rank 0's shard: cross-check the GPU result on it
             n = min(args.cpu_tracks, B)
