@@ -1498,8 +1498,13 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_mean = b->sm_mean;
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
-    // gains can be shared between the passes only when both use the same rates (see ukf_predict<kGains>)
-    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts) ? nullptr : b->rts_work;
+    // gains can be shared between the passes only when both use the same rates (see ukf_predict<kGains>) and when the
+    // caller's sigma-fan constants satisfy the two identities the compact work rows are built on: weights that sum to
+    // one (P_b from the predicted covariance) and 2 wi fan_scale = 1 (D[:, 2:4] = P_k[:, 2:4]).  unscented.py:95,125,132
+    // give both once compute_weights has run; a fan drawn before that (scale = n, HostBatch.weights_computed = False)
+    // does not, and then the smoother recomputes everything.
+    const bool identities = fabs(2.0 * b->wi * b->fan_scale - 1.0) <= 1e-14 && fabs(b->w0 + 8.0 * b->wi - 1.0) <= 1e-14;
+    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts || !identities) ? nullptr : b->rts_work;
     return STE_OK;
 }
 

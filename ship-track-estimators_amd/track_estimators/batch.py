@@ -351,6 +351,13 @@ class DeviceBatch:
         s.status = self.status.data_ptr()
         s.rts_work = None if self.rts_work is None else self.rts_work.data_ptr()
         self.struct = s
+        # The uploads above were queued on the current stream.  One event, recorded now, is what other streams wait on
+        # before the first launch (SmootherPipeline.submit): waiting on the current stream *at submit time* would put a
+        # marker on the legacy default stream, which every blocking stream synchronises with -- a device-wide barrier in
+        # the middle of a pipelined sequence (two of them cost a --steps 20 --warmup 5 run 10 of its 32 ms in round 2).
+        self._uploaded = torch.cuda.Event()
+        self._uploaded.record(torch.cuda.current_stream(self.device))
+        self._pipeline_done = None
 
     def _stream(self, stream):
         if stream is None:
@@ -379,6 +386,8 @@ class DeviceBatch:
         host allocator recycles it once they are dropped, so only a process's first large download pays for pinning).
         10 000 x 500 with all four histories: 1.6 GB, ~35 ms over PCIe gen 5 instead of ~170 ms through pageable memory."""
         torch = self.torch
+        if self._pipeline_done is not None:  # results of a SmootherPipeline.submit still in flight on another stream
+            torch.cuda.current_stream(self.device).wait_event(self._pipeline_done)
         out, pending = {}, []
         for name in names:
             attr, width = self._OUT[name]
@@ -406,6 +415,8 @@ class DeviceBatch:
         return d["means_smoothed"], d["covs_smoothed"]
 
     def status_host(self):
+        if self._pipeline_done is not None:
+            self._pipeline_done.synchronize()
         return self.status.cpu().numpy()
 
 
@@ -419,8 +430,8 @@ class SmootherPipeline:
     the first ``forward_cus`` compute units and smoothers on streams restricted to the rest
     (``ste_stream_create_cu_range``).  By default the forward passes run with one lane per track (``forward_lanes``):
     157 waves per 10 000-track batch, half the instructions per track of the quad mapping that is best for a batch on
-    its own, and five of them in flight fill the 640 SIMDs of a 160-CU partition; the smoothers of two batches share
-    the other 96 CUs, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
+    its own, and as many of them in flight as fill the partition's SIMDs (``forward_streams``: four at 10 000 tracks on
+    160 CUs); the smoothers of two batches share the other CUs, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
     its histories and work rows; a batch is not resubmitted before its previous smoother has finished (events), so the
     caller rotates through ``buffers_needed`` or more of them.
 
@@ -452,6 +463,8 @@ class SmootherPipeline:
             # ~160 CU-ms, a quad-per-track one ~280: five eighths of the chip for the former (160 + 96 CUs: 1.17 ms per
             # step at 10 000 tracks; 144 + 112: 1.34, 168 + 88: 1.45), three quarters for the latter (192 + 64: 1.49).
             forward_cus = (ncu * (3 if quad else 5) // (4 if quad else 8)) // 8 * 8
+            # small devices / partitioned compute modes: keep at least one CU on either side of the split
+            forward_cus = max(1, min(forward_cus if forward_cus > 0 else ncu // 2, ncu - 1))
         if forward_streams is None:
             # as many forward passes in flight as fill the partition's wave slots: a lane-per-track wave holds a SIMD's
             # whole register file, quad-per-track waves (256 VGPRs) fit two to a SIMD.  Quad passes: rounded up (the waves
@@ -469,7 +482,9 @@ class SmootherPipeline:
         self.forward_cus, self.smoother_cus = int(forward_cus), int(ncu - forward_cus)
         self._raw = []
         self.fwd_streams, self.bwd_streams = [], []
-        self._tail_stream = None
+        # unrestricted stream for the smoother of the last batch of a sequence; created here, not at first use, so
+        # that a timed sequence never pays for it
+        self._tail_stream = torch.cuda.Stream(self.device)
         self._count = 0
         self._batches = []  # weak references to the DeviceBatches that carry one of this pipeline's events
         self.buffers_needed = forward_streams + smoother_streams + 1
@@ -491,6 +506,7 @@ class SmootherPipeline:
         # that order ended every pipelined run of round 1 in a SIGSEGV inside __cxa_finalize.  So the streams are
         # destroyed while everything is still up: close() / the context manager / __del__, and at the latest atexit.
         _live_pipelines.add(self)
+        _register_atexit()
 
     # single-stream names kept for callers that look at them
     @property
@@ -518,14 +534,14 @@ class SmootherPipeline:
         fwd_stream = self.fwd_streams[k % len(self.fwd_streams)]
         bwd_stream = self.bwd_streams[k % len(self.bwd_streams)]
         if final:
-            if self._tail_stream is None:
-                self._tail_stream = torch.cuda.Stream(self.device)
             bwd_stream = self._tail_stream
         done = getattr(db, "_pipeline_done", None)
         if done is not None:
             fwd_stream.wait_event(done)  # the previous use of these buffers has drained
         else:
-            fwd_stream.wait_stream(torch.cuda.current_stream(self.device))  # uploads queued by the constructor
+            # uploads queued by the constructor: an event it recorded then.  (Not wait_stream(current stream): that
+            # records on the legacy default stream, which drains every blocking stream -- this pipeline's included.)
+            fwd_stream.wait_event(db._uploaded)
         if timing is not None:
             timing[0].record(fwd_stream)
         # Lane mapping of the forward pass: with several passes sharing the partition a lane per track is the better
@@ -600,15 +616,25 @@ class SmootherPipeline:
 
 
 _live_pipelines = weakref.WeakSet()
+_atexit_registered = False
 
 
-@atexit.register
 def _close_live_pipelines():
     for pipe in list(_live_pipelines):
         try:
             pipe.close()
         except Exception:
             pass
+
+
+def _register_atexit():
+    # Registered when the first pipeline is built, i.e. after torch has been imported: atexit runs handlers in reverse
+    # order of registration, so this one runs BEFORE torch's own teardown and the streams are destroyed while the HIP
+    # runtime, torch and any profiler tool are still up.
+    global _atexit_registered
+    if not _atexit_registered:
+        atexit.register(_close_live_pipelines)
+        _atexit_registered = True
 
 
 def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: str = "wgs84", device="cuda:0"):

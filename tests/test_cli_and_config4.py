@@ -291,3 +291,51 @@ def test_bench_two_rank_control_flow():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "track-steps/s"
     assert out["config"]["tracks_per_gpu"] == 256 and "all-gather" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["status_flagged_tracks"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no external launcher (the form the driver's N = 1 command has): bench.py must start
+    the two ranks itself -- as a child job, before it touches the GPU -- relay rank 0's one JSON line and exit 0."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["STE_BENCH_BACKEND"] = "gloo"  # two ranks share this box's one GPU
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--tracks", "256",
+           "--cpu-tracks", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["total_tracks"] == 512 and out["value"] > 0
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """CPU side of the same: the child command is the driver's own launch line around this script and its arguments."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
