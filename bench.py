@@ -214,6 +214,7 @@ def _main(stack):
     ap.add_argument("--forward-streams", type=int, default=None)
     ap.add_argument("--smoother-streams", type=int, default=None)
     ap.add_argument("--forward-lanes", type=int, default=None, help="lane mapping of the pipelined forward passes (1, 4, 0)")
+    ap.add_argument("--shared", action="store_true", help="no CU partition: forward passes and smoothers share every CU")
     ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
     ap.add_argument("--no-gp", action="store_true",
                     help="skip the `extra.gp_config4` entry (BASELINE configs[4]: one batched GP objective at 1000 x 2000, "
@@ -282,7 +283,7 @@ def _main(stack):
         try:
             kw = {k: v for k, v in (("forward_cus", args.forward_cus), ("forward_streams", args.forward_streams),
                                     ("smoother_streams", args.smoother_streams),
-                                    ("forward_lanes", args.forward_lanes)) if v is not None}
+                                    ("forward_lanes", args.forward_lanes), ("shared", args.shared or None)) if v is not None}
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)

@@ -43,8 +43,7 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 200 /* 0.2.0: flags LANES_1/LANES_4 and field `tuning` replace ste_set_lanes_per_track and
-                           STE_FLAG_SMOOTHER_LANE_PER_TRACK; STE_STATUS_BAD_INDEX; repeatable backward pass */
+#define STE_VERSION 300 /* 0.3.0: rts_work rows hold the smoother gain (30 doubles); sigma weights must sum to one */
 
 /* error codes */
 #define STE_OK 0
@@ -60,7 +59,7 @@ extern "C" {
 #define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
                                 the reference ships with its call site commented out, :228) */
 
-#define STE_RTS_WORK_ROWS 22 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work */
+#define STE_RTS_WORK_ROWS 30 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work */
 
 /* status[] bits (per track) */
 #define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
@@ -81,8 +80,8 @@ typedef struct ste_ukf_batch_f64 {
     int32_t Tmax;  /* padded number of observations (columns of ShipTrack.z) */
     int32_t n;     /* state dimension, must be 4 */
     uint32_t flags;
-    int32_t tuning; /* 0 = defaults.  Experiments / tests: bits 0-7 = gain (producer) waves per smoother workgroup (1..4),
-                       bit 8 = every smoother gain by the eigenvalue route (default: only near-singular P_b) */
+    int32_t tuning; /* 0 = defaults.  Tests: bit 8 = every smoother gain by the eigenvalue route (default: only where P_b is
+                       close to singular); other bits are ignored */
 
     /* sigma-fan constants, computed by the host exactly as unscented.py:95,125,132 does (HOST values) */
     double fan_scale; /* n / (1 - W0) */
@@ -122,15 +121,14 @@ typedef struct ste_ukf_batch_f64 {
     int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
 
     /*
-     * Optional workspace [Nmax][22][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts == cog_rate_rts ==
-     * NULL, ste_ukf_forward_f64 also evaluates the smoother's per-step back-prediction x_b, P_b and cross-covariance D
-     * (which depend only on the filtered state of step k, unscented.py:297-330) while it has the sigma points in
-     * registers and stores them here (row k: x_b 4 | P_b upper triangle 10 | columns 0-1 of D 8; columns 2-3 of D equal
-     * columns 2-3 of the filtered covariance because speed and heading pass through the process model with unit slope).
-     * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) on the fly and runs the
-     * recurrence (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Tracks
-     * whose forward status carries CLAMPED or NOCONV (the identity for D's last columns needs an exact square root) are
-     * smoothed by the stand-alone kernel in the same call.  Results are those of the stand-alone smoother to rounding.
+     * Optional workspace [Nmax][STE_RTS_WORK_ROWS][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts ==
+     * cog_rate_rts == NULL, ste_ukf_forward_f64 also evaluates what the smoother's step k needs of the sigma fan of the
+     * filtered state of step k (unscented.py:297-333: back-prediction x_b, P_b, cross-covariance D) while it has that fan
+     * in registers, forms the gain K = D pinv(P_b) (:333) and stores it here (row k: K 16 | x_b 4 | P_b upper triangle 10;
+     * x_b and P_b only for the steps where they do not follow from rows k and k + 1 of the filtered history, i.e. steps
+     * followed by an update, row 0 of a run that starts with one, runs with recorded noise).  ste_urtss_backward_f64 on
+     * the same batch is then the recurrence of :337-349 alone; it only reads the workspace, so it may be called again on
+     * the same forward result.  Results are those of the stand-alone smoother to rounding.
      * NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history was not
      * produced by ste_ukf_forward_f64 on this batch).
      */

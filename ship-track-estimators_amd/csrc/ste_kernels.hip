@@ -23,6 +23,7 @@
 #include "../../include/ste.h"
 #include "ste_err.h"
 #include "ste_math.h"
+#include "ste_lane.h"
 #include "ste_quad.h"
 
 namespace ste {
@@ -31,6 +32,7 @@ struct KParams {
     int B, Nmax, Tmax;
     unsigned flags;
     int tuning;
+    int fast_upd;  // H = diag(1, 1, 0, 0), R confined to the same block, no robust rescaling: closed-form update
     Mats m;
     const int32_t* nsteps;
     const double* x0;
@@ -55,13 +57,16 @@ struct KParams {
 
 constexpr int kColdEvery = 64;  // power of two
 
-// rts_work row layout: x_b (4) | P_b upper triangle, row-major (10) | columns 0-1 of D, row-major (8).
-// Columns 2-3 of the cross-covariance D are not stored: speed and heading go through the process model with unit slope
-// (non_linear_process.py:74-75), so with T = sqrtm(scale P) and the symmetric fan D[:, 2:4] = 2 wi (T T)[:, 2:4] =
-// P_k[:, 2:4] (2 wi scale = 1 for every n and W0, unscented.py:95,132) -- the filtered covariance the smoother reads
-// anyway.  That identity needs T T = scale P, i.e. an unclamped, converged square root: tracks whose forward status
-// carries CLAMPED or NOCONV are smoothed again by the stand-alone kernel (launch_backward).
-constexpr int kWorkXb = 0, kWorkPb = 4, kWorkD = 14, kWorkElems = 22;
+// rts_work row layout (round 3): K (16, row-major) | x_b (4) | P_b upper triangle, row-major (10).
+// The forward kernels form the smoother's gain K = D pinv(P_b) themselves (unscented.py:297-333: the smoother's step k starts
+// from the same filtered state as the forward predict of step k, with the same dt and rates, so its fan, its back-
+// prediction x_b, its P_b and its cross-covariance D are values the predict already holds), which leaves the backward pass
+// a pure recurrence (unscented.py:337-349).  x_b and P_b, which the recurrence needs as well, are written only for the
+// steps where they cannot be rebuilt from the filtered history -- steps followed by a measurement update, row 0 when the
+// run starts with an update, and every step of a run with recorded noise; elsewhere x_b = fwd_mean[k + 1] and
+// P_b = fwd_cov[k + 1] + b b^T with b = fwd_mean[k + 1] - fwd_mean[k].
+constexpr int kWorkK = 0, kWorkXb = 16, kWorkPb = 20, kWorkElems = STE_RTS_WORK_ROWS;
+static_assert(kWorkElems == 30, "include/ste.h: STE_RTS_WORK_ROWS");
 
 __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
     STE_UNROLL
@@ -292,56 +297,26 @@ __device__ __forceinline__ void weighted_outer(const double (&a)[9][4], const do
     }
 }
 
-// UKF predict (unscented.py:178-207).  x, P updated in place.
-//
-// kGains: the smoother's step k (unscented.py:297-333) starts from the same filtered (x_k, P_k), builds the same sigma
-// fan and pushes it through the same process model with the same dt and rates, so its back-prediction x_b, its P_b
-// (centred on x_k, :324-325), its cross-covariance D (:328-330) and its gain K = D pinv(P_b) (:333) are functions of
-// values this predict already holds.  They are computed here, once, and written to rts_work; the backward pass is
-// then only the sequential recurrence (:337-349).  Valid when the smoother's rates equal the forward rates
-// (sog_rate_rts == NULL); otherwise the stand-alone backward kernel recomputes everything.
-template <bool kGains, bool kWarm>
+// UKF predict (unscented.py:178-207), the literal form: the whole fan, the weighted mean, the weighted outer products.
+// x, P updated in place.  Used by the single-step entry point (ste_ukf_predict_f64); the forward kernels run the streamed
+// form of the same arithmetic (lane_predict / quad_predict).
 __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double (&P)[4][4], double dt, double sr,
-                                           double cr, const double* noise, size_t nrow, size_t B, size_t t,
-                                           const double* noise_rts, double* work, EigBasis& fan_basis,
-                                           EigBasis& pb_basis) {
-    (void)pb_basis;
+                                           double cr, const double* noise, size_t nrow, size_t B, size_t t) {
     double sig[9][4], sig0[9][4], T[4][4];
-    int st = sym_sqrt4<kWarm>(P, p.fan_scale, T, fan_basis);
-    if (kWarm) fan_basis.valid = true;
+    EigBasis none;
+    const int st = sym_sqrt4<false>(P, p.fan_scale, T, none);
     propagate_points(x, T, dt, sr, cr, sig0, sig);
-    double m[4];
+    double xp[4];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
         double acc = 0.0;
         STE_UNROLL
         for (int j = 1; j < 9; ++j) acc += sig[j][c];
-        m[c] = fma(p.w0, sig[0][c], p.wi * acc);
+        xp[c] = fma(p.w0, sig[0][c], p.wi * acc);
     }
-    double xp[4];
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) xp[c] = m[c];
     if (noise) {
         STE_UNROLL
         for (int c = 0; c < 4; ++c) xp[c] += noise[(nrow * 4 + c) * B + t];
-    }
-    // the two columns of the cross-covariance the smoother needs (see kWorkD), while the points are still whole:
-    // chi_0 - x_k = 0 and chi_{i+-} - x_k = +-T_i, so D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T and x_b cancels
-    double D2[4][2];
-    if (kGains && work) {
-        STE_UNROLL
-        for (int c = 0; c < 2; ++c) {
-            double dl[4];
-            STE_UNROLL
-            for (int i = 0; i < 4; ++i) dl[i] = sig[1 + i][c] - sig[5 + i][c];
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                double acc = T[r][0] * dl[0];
-                STE_UNROLL
-                for (int i = 1; i < 4; ++i) acc = fma(T[r][i], dl[i], acc);
-                D2[r][c] = p.wi * acc;
-            }
-        }
     }
     STE_UNROLL
     for (int j = 0; j < 9; ++j) {
@@ -352,47 +327,9 @@ __device__ __forceinline__ int ukf_predict(const Mats& p, double (&x)[4], double
     weighted_outer<true>(sig, sig, p.w0, p.wi, Pn);
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) Pn[r][c] += p.Q[r * 4 + c];
-    }
-    if (kGains && work) {
-        // P_b is centred on the filtered mean x_k, not on the predicted one (unscented.py:324-325).  With b = x^- - x_k
-        // and e = (weighted mean) - x^- (minus the injected predict noise) and weights that sum to one,
-        //   P_b = sum W (chi' - x_k)(chi' - x_k)^T + Q = P^- + e b^T + b e^T + b b^T.
-        double xb[4], bv[4];
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) {
-            xb[c] = m[c];
-            bv[c] = xp[c] - x[c];
-        }
-        if (noise_rts) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) xb[c] += noise_rts[(nrow * 4 + c) * B + t];
-        }
-        double* w = work + (nrow * kWorkElems) * B + t;
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) st_stream(&w[(kWorkXb + c) * B], xb[c]);
-        int e = kWorkPb;
-        STE_UNROLL
-        for (int r = 0; r < 4; ++r) {
-            STE_UNROLL
-            for (int c = r; c < 4; ++c) {
-                double v = fma(bv[r], bv[c], Pn[r][c]);
-                if (noise) v += fma(m[r] - xp[r], bv[c], bv[r] * (m[c] - xp[c]));
-                st_stream(&w[(e++) * B], v);
-            }
-        }
-        STE_UNROLL
-        for (int r = 0; r < 4; ++r) {
-            STE_UNROLL
-            for (int c = 0; c < 2; ++c) st_stream(&w[(kWorkD + r * 2 + c) * B], D2[r][c]);
-        }
-    }
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
         x[r] = xp[r];
         STE_UNROLL
-        for (int c = 0; c < 4; ++c) P[r][c] = Pn[r][c];
+        for (int c = 0; c < 4; ++c) P[r][c] = Pn[r][c] + p.Q[r * 4 + c];
     }
     return st;
 }
@@ -534,62 +471,257 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward pass, one lane per track
+// forward pass, one lane per track (ste_lane.h)
 // ---------------------------------------------------------------------------------------------------------------
+// UKF predict (unscented.py:178-207) on packed (x, P), the sigma pairs streamed through running moments; with `work` it
+// also leaves the smoother's row of this step (see kWorkK).  x, P are replaced by the predicted mean (+ recorded noise)
+// and covariance.
 template <bool kGains>
-__global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
+__device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], double (&P)[10], double (&V)[4][4], bool warm,
+                                            double dt, double sr, double cr, const double* noise,
+                                            const double* noise_rts, size_t nrow, size_t B, size_t t, double* work,
+                                            bool full_row, bool all_eig) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double T[10];
+    const int st = sym_sqrt_p(P, p.fan_scale, T, V, warm);
+    bool ok = true;
+    FanCentre g;
+    fan_centre(x, dt, sr, cr, g, ok);
+    FanMoments f;
+    moments_clear(f);
+    {
+        double lonp, latp, lonm, latm;
+        fan_pair<0>(x, T, g, lonp, latp, lonm, latm, ok);
+        moments_add<0, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
+        fan_pair<1>(x, T, g, lonp, latp, lonm, latm, ok);
+        moments_add<1, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
+        fan_pair<2>(x, T, g, lonp, latp, lonm, latm, ok);
+        moments_add<2, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
+        fan_pair<3>(x, T, g, lonp, latp, lonm, latm, ok);
+        moments_add<3, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
+    }
+    if (__builtin_expect(__any(!ok), 0)) {
+        // Some lane left the validity range of the branch-free transcendentals (a pole, a step of tens of degrees,
+        // non-finite data): the whole fan again with the branching version (device-library sincos / atan2 / asin, out
+        // of line, through copies so that the hot path's arrays stay in registers), same formulas for the lanes that
+        // were fine, then the same moment sums.
+        double xc[4], Tc[4][4], s0c[9][4], sc[9][4];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            xc[r] = x[r];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Tc[r][c] = T[tix(r, c)];
+        }
+        propagate_fan_branching(xc, Tc, dt, sr, cr, s0c, sc);
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) g.c[c] = sc[0][c];
+        moments_clear(f);
+        moments_add<0, kGains>(f, T, g.c[0], g.c[1], sc[1][0], sc[1][1], sc[5][0], sc[5][1]);
+        moments_add<1, kGains>(f, T, g.c[0], g.c[1], sc[2][0], sc[2][1], sc[6][0], sc[6][1]);
+        moments_add<2, kGains>(f, T, g.c[0], g.c[1], sc[3][0], sc[3][1], sc[7][0], sc[7][1]);
+        moments_add<3, kGains>(f, T, g.c[0], g.c[1], sc[4][0], sc[4][1], sc[8][0], sc[8][1]);
+    }
+    // weighted mean and covariance about it: the weights sum to one (make_params refuses anything else), the centre's
+    // deviation is zero, so mean = c' + wi s and cov = wi S - (wi s)(wi s)^T
+    const double d0 = p.wi * f.s0, d1 = p.wi * f.s1;
+    const double m[4] = {g.c[0] + d0, g.c[1] + d1, g.c[2], g.c[3]};
+    double xp[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xp[c] = m[c];
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) xp[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    const double two_wi = p.wi + p.wi;
+    double Pn[10];
+    Pn[tix(0, 0)] = fma(-d0, d0, p.wi * f.S[tix(0, 0)]);
+    Pn[tix(0, 1)] = fma(-d0, d1, p.wi * f.S[tix(0, 1)]);
+    Pn[tix(1, 1)] = fma(-d1, d1, p.wi * f.S[tix(1, 1)]);
+    Pn[tix(0, 2)] = p.wi * f.S[tix(0, 2)];
+    Pn[tix(0, 3)] = p.wi * f.S[tix(0, 3)];
+    Pn[tix(1, 2)] = p.wi * f.S[tix(1, 2)];
+    Pn[tix(1, 3)] = p.wi * f.S[tix(1, 3)];
+    Pn[tix(2, 2)] = two_wi * f.S[tix(2, 2)];
+    Pn[tix(2, 3)] = two_wi * f.S[tix(2, 3)];
+    Pn[tix(3, 3)] = two_wi * f.S[tix(3, 3)];
+    // The smoother's cross-covariance D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T (the centre's deviation from x_k is zero
+    // and x_b cancels in the difference), while the moments are at hand: rows 2-3 of its columns 0-1 are the cross moments
+    // S[c][2], S[c][3] just formed (Pn before Q is added); speed and heading pass through the process model with unit
+    // slope, so its columns 2-3 are 2 wi (T T)[:, 2:4].
+    double D[4][4];
+    if (kGains && work) {
+        D[0][0] = p.wi * f.Dn[0][0];
+        D[0][1] = p.wi * f.Dn[0][1];
+        D[1][0] = p.wi * f.Dn[1][0];
+        D[1][1] = p.wi * f.Dn[1][1];
+        D[2][0] = Pn[tix(0, 2)];
+        D[2][1] = Pn[tix(1, 2)];
+        D[3][0] = Pn[tix(0, 3)];
+        D[3][1] = Pn[tix(1, 3)];
+        D[0][2] = two_wi * f.TT[0][0];
+        D[0][3] = two_wi * f.TT[0][1];
+        D[1][2] = two_wi * f.TT[1][0];
+        D[1][3] = two_wi * f.TT[1][1];
+        D[2][2] = Pn[tix(2, 2)];
+        D[2][3] = Pn[tix(2, 3)];
+        D[3][2] = Pn[tix(2, 3)];
+        D[3][3] = Pn[tix(3, 3)];
+    }
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) Pn[tix(r, c)] += p.Q[r * 4 + c];
+    }
+    if (noise) {  // the covariance is taken about the noised mean (unscented.py:203-205): + e e^T, e = mean - x^-
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = r; c < 4; ++c) Pn[tix(r, c)] = fma(m[r] - xp[r], m[c] - xp[c], Pn[tix(r, c)]);
+        }
+    }
+    int gst = 0;
+    if (kGains && work) {
+        // P_b is centred on the filtered mean x_k, not on the predicted one (unscented.py:324-325): with b = x^- - x_k,
+        // e = (weighted mean) - x^-,  P_b = P^- + e b^T + b e^T + b b^T; then the gain K = D pinv(P_b) (:333)
+        double* w = work + (nrow * kWorkElems) * B + t;
+        double bv[4], Pb[10], K[4][4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) bv[c] = xp[c] - x[c];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = r; c < 4; ++c) {
+                double v = fma(bv[r], bv[c], Pn[tix(r, c)]);
+                if (noise) v += fma(m[r] - xp[r], bv[c], bv[r] * (m[c] - xp[c]));
+                Pb[tix(r, c)] = v;
+            }
+        }
+        gst = smoother_gain(Pb, D, all_eig, K);
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) st_stream(&w[(kWorkK + r * 4 + c) * B], K[r][c]);
+        }
+        if (full_row) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                double xb = m[c];
+                if (noise_rts) xb += noise_rts[(nrow * 4 + c) * B + t];
+                st_stream(&w[(kWorkXb + c) * B], xb);
+            }
+            STE_UNROLL
+            for (int e = 0; e < 10; ++e) st_stream(&w[(kWorkPb + e) * B], Pb[e]);
+        }
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) x[c] = xp[c];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) P[e] = Pn[e];
+    return st | gst;
+}
+
+// Measurement update on packed (x, P): the closed form for H = diag(1, 1, 0, 0) (kFastUpd, chosen by launch_forward from
+// the matrices), otherwise the general 4x4 route (any H, R; the opt-in robust rescaling).
+template <bool kFastUpd>
+__device__ __forceinline__ int lane_update(const Mats& p, double (&x)[4], double (&P)[10], const double (&zin)[4],
+                                           const double* noise, size_t nrow, size_t B, size_t t) {
+    if (kFastUpd) {
+        double z[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) z[c] = zin[c];
+        if (noise) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
+        }
+        lane_update_sel2(p.R[0], p.R[1], p.R[5], x, P, z);
+        return 0;
+    } else {
+        double Pf[4][4];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Pf[r][c] = P[tix(r, c)];
+        }
+        const int st = ukf_update(p, x, Pf, zin, noise, nrow, B, t);
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = r; c < 4; ++c) P[tix(r, c)] = Pf[r][c];
+        }
+        return st;
+    }
+}
+
+__device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t B, size_t t, const double (&x)[4],
+                                           const double (&P)[10]) {
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) st_stream(&p.fwd_mean[(row * 4 + c) * B + t], x[c]);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) st_stream(&p.fwd_cov[(row * 16 + r * 4 + c) * B + t], P[tix(r, c)]);
+    }
+}
+
+// One wave per SIMD, on purpose: the step loop issues a vector instruction in ~80 % of its cycles, so a second forward
+// wave on the same SIMD gains next to nothing (measured: two per SIMD run 1.55x slower each), while waves of several
+// passes that the dispatcher doubles up on some SIMDs leave others empty.  amdgpu_waves_per_eu(1, 1) makes the
+// compiler pad the allocation to 264 registers: a second forward wave no longer fits, a smoother wave (<= 248) does.
+template <bool kGains, bool kFastUpd>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= B) return;
     const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
 
-    double x[4], P[4][4];
+    double x[4], P[10];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) x[c] = p.x0[c * B + t];
-    if (p.flags & STE_FLAG_SHARED_P0) {
+    {
+        // the prior enters as (P0 + P0^T) / 2: the host refuses a P0 that is not symmetric (batch._as44)
+        double Pf[4][4];
+        if (p.flags & STE_FLAG_SHARED_P0) {
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) Pf[r][c] = p.P0[r * 4 + c];
+            }
+        } else {
+            load_mat(p.P0, 0, B, t, Pf);
+        }
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
-            for (int c = 0; c < 4; ++c) P[r][c] = p.P0[r * 4 + c];
+            for (int c = r; c < 4; ++c) P[tix(r, c)] = 0.5 * (Pf[r][c] + Pf[c][r]);
         }
-    } else {
-        load_mat(p.P0, 0, B, t, P);
     }
-    // slot 0 = prior (kalman_filter.py:76-77)
-    store_vec(p.fwd_mean, 0, B, t, x);
-    store_mat(p.fwd_cov, 0, B, t, P);
+    store_hist(p, 0, B, t, x, P);  // slot 0 = prior (kalman_filter.py:76-77)
 
     int st = 0;
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
+    const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
+    const bool all_eig = (p.tuning & 0x100) != 0;
+    double V[4][4];
     if (kGains && initial_update && ns > 0) {
         // History row 0 is the PRIOR (kalman_filter.py:76-77) while the first predict starts from the state after the
         // initial update, so the smoother's step 0 (which reads row 0, unscented.py:301) needs its own fan: run the
-        // predict arithmetic once on a copy of the prior, keep only the gains.
-        double xc[4], Pc[4][4];
+        // predict arithmetic once on a copy of the prior, keep only the smoother's rows.
+        double xc[4], Pc[10];
         STE_UNROLL
-        for (int r = 0; r < 4; ++r) {
-            xc[r] = x[r];
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) Pc[r][c] = P[r][c];
-        }
-        EigBasis c0, c1;
-        st |= ukf_predict<true, false>(p.m, xc, Pc, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, 0, B, t,
-                                       p.noise_rts, p.rts_work, c0, c1);
+        for (int c = 0; c < 4; ++c) xc[c] = x[c];
+        STE_UNROLL
+        for (int e = 0; e < 10; ++e) Pc[e] = P[e];
+        st |= lane_predict<true>(p.m, xc, Pc, V, false, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts, 0, B, t,
+                                 p.rts_work, true, all_eig);
     }
     if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
-        st |= ukf_update(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+        st |= lane_update<kFastUpd>(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
 
-    // Eigenvector bases of the two matrices decomposed every step (3P for the fan, P_b for the smoother gain): the
-    // next step's Jacobi solve starts from them.  Restarted from the identity every kColdEvery steps so rounding in
-    // the accumulated rotations cannot build up over a long track.
-    EigBasis fan_basis, pb_basis;
-    fan_basis.valid = false;
-    pb_basis.valid = false;
-
-    // inputs of step 0
+    // The eigenvectors of the fan matrix carry over from step to step (warm start); restarted from the identity every
+    // kColdEvery steps so that rounding in the accumulated rotations cannot build up over a long track.
     double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
     int ui_n = -1;
     if (ns > 0) {
@@ -604,33 +736,36 @@ __global__ __launch_bounds__(64) void ukf_forward_l1(const KParams p) {
         if (live) {
             const double dt = dt_n, sr = sr_n, cr = cr_n;
             const int ui = ui_n;
-            // observation for this step's update: address known now, used after the predict
-            double zk[4] = {0.0, 0.0, 0.0, 0.0};
+            // Unconditional loads with clamped indices: a load inside an `if` makes hipcc drain the queue with
+            // s_waitcnt vmcnt(0) where the branch rejoins.  The observation row of a step without an update is row 0
+            // (cache-resident); the inputs of step k + 1 stay in flight during this step's arithmetic.
             const bool ui_ok = ui < p.Tmax;  // an observation column past the padded batch: flagged, update skipped
-            if (ui >= 0 && ui_ok) load_vec(p.z, (size_t)ui, B, t, zk);
-            // inputs of step k+1: in flight during this step's arithmetic
-            if (k + 1 < ns) {
-                const size_t o = (size_t)(k + 1) * B + t;
+            const bool upd = ui >= 0 && ui_ok;
+            double zk[4];
+            load_vec(p.z, (size_t)(upd ? ui : 0), B, t, zk);
+            {
+                const size_t o = (size_t)(k + 1 < ns ? k + 1 : k) * B + t;
                 dt_n = p.dt[o];
                 sr_n = p.sog_rate[o];
                 cr_n = p.cog_rate[o];
                 ui_n = p.upd_idx[o];
             }
-            // row 0's gains were taken from the prior above; every later row k is the state this predict starts from
+            // row 0's smoother rows were taken from the prior above; every later row k is the state this predict starts from
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
-            if ((k & (kColdEvery - 1)) == 0) {
-                fan_basis.valid = false;
-                pb_basis.valid = false;
-            }
-            st |= ukf_predict<kGains, true>(p.m, x, P, dt, sr, cr, p.noise_pred, (size_t)k, B, t, p.noise_rts, work,
-                                            fan_basis, pb_basis);
-            if (ui >= 0 && ui_ok) st |= ukf_update(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            const bool warm = (k & (kColdEvery - 1)) != 0;
+            st |= lane_predict<kGains>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
+                                       upd || noise_mode, all_eig);
+            if (upd) st |= lane_update<kFastUpd>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
-            store_vec(p.fwd_mean, (size_t)k + 1, B, t, x);
-            store_mat(p.fwd_cov, (size_t)k + 1, B, t, P);
+            store_hist(p, (size_t)k + 1, B, t, x, P);
         }
     }
-    if (!all_finite(x, P)) st |= STE_STATUS_NAN;
+    double chk = 0.0;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) chk += x[c] * 0.0;
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) chk += P[e] * 0.0;
+    if (!(chk == 0.0)) st |= STE_STATUS_NAN;  // inf*0 and nan*0 are NaN
     p.status[t] = st;
 }
 
@@ -647,7 +782,8 @@ __device__ __forceinline__ int tri_index(int r, int c) { return r * 4 - (r * (r 
 // (= minus the injected predict noise; zero in noise-free runs), because the weights sum to one.
 __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
                                             QuadBasis& basis, double dt, double sr, double cr, const double* noise,
-                                            const double* noise_rts, double* work, size_t nrow, size_t B, size_t t) {
+                                            const double* noise_rts, double* work, size_t nrow, size_t B, size_t t,
+                                            bool full_row, bool all_eig) {
     double Tn[4], s0[4], sp[4], sm[4], m[4], xp[4];
     int st = quad_sym_sqrt(Px, p.fan_scale, cx, basis, Tn);
     quad_propagate(x, Tn, dt, sr, cr, s0, sp, sm);
@@ -695,14 +831,45 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
             for (int s = 0; s < 4; ++s) Pb[s] += fma(ex[0], bx[s], bx[0] * ex[s]);
         }
         double* w = work + (nrow * kWorkElems) * B + t;
-        w[(kWorkXb + q) * B] = sel4(xb, q);
+        // row q of D: columns 0-1 from the +- pair differences above, columns 2-3 = 2 wi (T T)[q][2:4] (speed and heading
+        // pass through the process model with unit slope)
+        double Dq[4];
+        Dq[0] = p.wi * D[0];
+        Dq[1] = p.wi * D[1];
         STE_UNROLL
-        for (int s = 0; s < 4; ++s) {
-            const int c = q ^ s;
-            if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pb[s];
+        for (int c = 2; c < 4; ++c) {
+            double acc = Tn[0] * bcast<0>(Tn[c]);
+            acc = fma(Tn[1], bcast<1>(Tn[c]), acc);
+            acc = fma(Tn[2], bcast<2>(Tn[c]), acc);
+            acc = fma(Tn[3], bcast<3>(Tn[c]), acc);
+            Dq[c] = (p.wi + p.wi) * acc;
         }
+        // the whole of P_b in every lane (natural order rows arrive by quad broadcasts), then this lane's row of
+        // K = D pinv(P_b) (unscented.py:333) by the same factorisation / eigenvalue routes as the lane-per-track kernel
+        double Pbn[4];
+        xorperm(Pb, q, Pbn);  // row q of P_b, natural order
+        double Pbp[10];
+        Pbp[tix(0, 0)] = bcast<0>(Pbn[0]);
+        Pbp[tix(0, 1)] = bcast<0>(Pbn[1]);
+        Pbp[tix(0, 2)] = bcast<0>(Pbn[2]);
+        Pbp[tix(0, 3)] = bcast<0>(Pbn[3]);
+        Pbp[tix(1, 1)] = bcast<1>(Pbn[1]);
+        Pbp[tix(1, 2)] = bcast<1>(Pbn[2]);
+        Pbp[tix(1, 3)] = bcast<1>(Pbn[3]);
+        Pbp[tix(2, 2)] = bcast<2>(Pbn[2]);
+        Pbp[tix(2, 3)] = bcast<2>(Pbn[3]);
+        Pbp[tix(3, 3)] = bcast<3>(Pbn[3]);
+        double Kq[4];
+        st |= quad_smoother_gain(Pbp, Dq, all_eig, Kq);
         STE_UNROLL
-        for (int c = 0; c < 2; ++c) w[(kWorkD + q * 2 + c) * B] = p.wi * D[c];
+        for (int c = 0; c < 4; ++c) w[(kWorkK + q * 4 + c) * B] = Kq[c];
+        if (full_row) {  // elsewhere the smoother rebuilds x_b and P_b from history rows k and k + 1 (see kWorkK)
+            w[(kWorkXb + q) * B] = sel4(xb, q);
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pbn[c];
+            }
+        }
     }
     STE_UNROLL
     for (int c = 0; c < 4; ++c) {
@@ -859,6 +1026,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     store_row(0);  // slot 0 = prior (kalman_filter.py:76-77)
 
     int st = 0;
+    const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
+    const bool all_eig = (p.tuning & 0x100) != 0;
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     if (kGains && initial_update && ns > 0) {
         // smoother step 0 reads history row 0 = the prior, not the state the first predict starts from
@@ -871,7 +1040,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
         QuadBasis cold;
         cold.valid = false;
         st |= quad_predict(p.m, cx, xc, Pc, cold, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts,
-                           p.rts_work, 0, B, t);
+                           p.rts_work, 0, B, t, true, all_eig);
     }
     if (initial_update) {
         double z0[4];
@@ -908,7 +1077,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             }
             if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
-            st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t);
+            st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t,
+                               (ui >= 0 && ui_ok) || noise_mode, all_eig);
             if (ui >= 0 && ui_ok) st |= quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_row((size_t)k + 1);
@@ -926,28 +1096,23 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // URTSS backward pass, one lane per track (unscented.py:285-351)
 // ---------------------------------------------------------------------------------------------------------------
-// kFlaggedOnly: redo just the tracks whose forward status says the square root of some step was clamped or did not
-// converge (the compact work rows of the fused path assume T T = scale P, see kWorkD); waves without such a track leave
-// at once, so on clean batches this launch costs a few microseconds.
-template <bool kFlaggedOnly>
+// The literal smoother: recomputes the fan, its nine great-circle steps and both pseudo-inverses per step.  Used when
+// there are no work rows from the forward pass (rts_work == NULL, smoother rates that differ from the forward rates, a
+// history that ste_ukf_forward_f64 did not write, fan constants off the identities the compact rows rely on).
 __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= B) return;
-    const bool mine = !kFlaggedOnly || (p.status[t] & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
-    if (kFlaggedOnly && !__any(mine)) return;
-    const int ns = mine ? (p.nsteps ? p.nsteps[t] : p.Nmax) : -1;  // -1: this lane only keeps the others company
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
     const double* srp = p.sog_rate_rts ? p.sog_rate_rts : p.sog_rate;
     const double* crp = p.cog_rate_rts ? p.cog_rate_rts : p.cog_rate;
 
     // row ns: smoothed = filtered
     double xs[4], Ps[4][4];
-    load_vec(p.fwd_mean, (size_t)(ns < 0 ? 0 : ns), B, t, xs);
-    load_mat(p.fwd_cov, (size_t)(ns < 0 ? 0 : ns), B, t, Ps);
-    if (mine) {
-        store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-        store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
-    }
+    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
+    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
 
     // filtered row of the first step to process, prefetched
     double xn[4] = {0, 0, 0, 0}, Pn[4][4] = {};
@@ -1053,220 +1218,167 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
         }
     }
     if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
-    if (mine && st) atomicOr(&p.status[t], st);
+    if (st) atomicOr(&p.status[t], st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// URTSS backward pass from the rows the forward pass left in rts_work (x_b, P_b, D of every step; unscented.py:297-330):
-// one workgroup per 64 tracks, lane = track in every wave.
-//   waves 1..NP ("producers")  K = D pinv(P_b) (unscented.py:333) for one step each of the next block of NP steps --
-//                              this does not depend on the recurrence, so it runs one block ahead of it;
-//   wave 0 ("consumer")        the sequential recurrence (unscented.py:337-349) over the block the producers finished
-//                              in the previous iteration, reading K and P_b from LDS.
-// K never goes to HBM and D is not overwritten, so the pass can be repeated; per track-step it reads 22 doubles of work
-// row + 18 of history (mean, upper triangle of the covariance, x_b) and writes the 20 of the smoothed row (the seven
-// covariance entries the producers read again are the consumer's own, one block earlier: L2 hits).  One barrier
-// per block of NP steps; two LDS buffers of NP x 26 x 64 doubles.  The consumer keeps the history rows of the next
-// block in flight (ring of NP rows, the slot index is the position in the block, so it is static after unrolling);
-// each producer keeps its next work row in flight.
+// URTSS backward pass from the rows the forward pass left in rts_work: the recurrence of unscented.py:337-349,
+//     y = x^s_{k+1} - x_b (heading wrapped),  x^s_k = x_k + K y,  P^s_k = P_k + K (P^s_{k+1} - P_b) K^T,
+// one lane per track.  The gain K comes from the work row; x_b and P_b from the work row where they were stored (see
+// kWorkK) and otherwise from the filtered rows k and k + 1 the recurrence reads anyway.  Per track-step it reads 16 + 14
+// doubles (K; mean and upper triangle of the filtered covariance), plus 14 on the steps that were followed by an
+// update, and writes the 20 of the smoothed row.  No LDS, no barriers: the kernel is a chain of ~170 fp64 instructions
+// per step whose loads are one row ahead; it is meant to run beside the forward passes of the next batches, whose
+// waves take the issue slots it leaves (batch.SmootherPipeline).  Only reads the work rows: repeatable.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSmoothLdsRow = 26;  // K (16) | P_b upper triangle (10), each [64 lanes]
+// Is work row k "full" (x_b and P_b stored)?  Mirrors the forward kernels' choice: full when the step was followed by a
+// measurement update (ui = upd_idx[k] names a valid observation), for row 0 of a run that starts with an update, and
+// throughout a run with recorded noise.
+__device__ __forceinline__ bool work_row_full(const KParams& p, int k, int ui, bool always_full) {
+    return always_full || (ui >= 0 && ui < p.Tmax) || (k == 0 && !(p.flags & STE_FLAG_NO_INITIAL_UPDATE));
+}
 
-struct HistRow {
-    double xk[4], Pk[10], xb[4];
+struct RecurRow {
+    double K[16], xk[4], Pk[10];  // gain of step k; filtered mean and covariance (packed) of row k
 };
-__device__ __forceinline__ void load_hist_row(const KParams& p, size_t k, size_t B, size_t t, HistRow& g) {
+__device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_t B, size_t t, RecurRow& g) {
+    const double* w = p.rts_work + (k * kWorkElems) * B + t;
+    STE_UNROLL
+    for (int e = 0; e < 16; ++e) g.K[e] = w[(kWorkK + e) * B];
     load_vec(p.fwd_mean, k, B, t, g.xk);
-    int e = 0;
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
-        for (int c = r; c < 4; ++c) g.Pk[e++] = p.fwd_cov[(k * 16 + r * 4 + c) * B + t];
+        for (int c = r; c < 4; ++c) g.Pk[tix(r, c)] = p.fwd_cov[(k * 16 + r * 4 + c) * B + t];
     }
-    const double* w = p.rts_work + (k * kWorkElems) * B + t;
-    STE_UNROLL
-    for (int c = 0; c < 4; ++c) g.xb[c] = w[(kWorkXb + c) * B];
 }
 
-struct WorkRow {
-    double Pb[10], D2[8], Pc[7];  // Pc: filtered covariance entries (0,2) (0,3) (1,2) (1,3) (2,2) (2,3) (3,3) = columns 2-3 of D
-};
-__device__ __forceinline__ void load_work_row(const KParams& p, size_t k, size_t B, size_t t, WorkRow& g) {
-    const double* w = p.rts_work + (k * kWorkElems) * B + t;
-    STE_UNROLL
-    for (int e = 0; e < 10; ++e) g.Pb[e] = w[(kWorkPb + e) * B];
-    STE_UNROLL
-    for (int e = 0; e < 8; ++e) g.D2[e] = w[(kWorkD + e) * B];
-    constexpr int idx[7] = {2, 3, 6, 7, 10, 11, 15};
-    STE_UNROLL
-    for (int e = 0; e < 7; ++e) g.Pc[e] = p.fwd_cov[(k * 16 + idx[e]) * B + t];
-}
-
-template <int NP, bool kEigGains>
-__global__ __launch_bounds__((NP + 1) * 64) void urtss_smooth_wg(const KParams p) {
-    __shared__ double lds[2 * NP * kSmoothLdsRow * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     const size_t B = (size_t)p.B;
-    const size_t t_raw = (size_t)blockIdx.x * 64 + lane;
-    const bool valid = t_raw < B;
-    const size_t t = valid ? t_raw : B - 1;  // idle lanes shadow the last track (loads only) and take part in the barriers
-    const int ns = valid ? (p.nsteps ? p.nsteps[t] : p.Nmax) : 0;
-    int nsmax = ns;
-    STE_UNROLL
-    for (int off = 32; off >= 1; off >>= 1) nsmax = max(nsmax, __shfl_xor(nsmax, off, 64));
-    const int nblk = (nsmax + NP - 1) / NP;  // the same in every wave of the workgroup: they hold the same 64 tracks
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= B) return;
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    const bool always_full = p.noise_pred || p.noise_upd || p.noise_rts;
     const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
-    auto slot = [&](int blk, int i) -> double* { return lds + ((size_t)((blk & 1) * NP + i) * kSmoothLdsRow) * 64 + lane; };
-    int st = 0;
+    auto clampk = [&](int k) -> int { return min(max(k, 0), last_row); };
 
-    if (wave == 0) {
-        // ---- consumer: the recurrence ---------------------------------------------------------------------------
-        double xs[4], Ps[4][4];
-        load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
-        load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
-        if (valid) {  // row ns: smoothed = filtered
-            store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-            store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
-        }
-        HistRow ring[NP];
-        if (nblk > 0) {
+    // row ns: smoothed = filtered; it is also "filtered row k + 1" of the first step
+    double xs[4], Ps[10], xn[4], Pn[10];
+    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) Ps[tix(r, c)] = p.fwd_cov[((size_t)ns * 16 + r * 4 + c) * B + t];
+    }
+    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) st_stream(&p.sm_cov[((size_t)ns * 16 + r * 4 + c) * B + t], Ps[tix(r, c)]);
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xn[c] = xs[c];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) Pn[e] = Ps[e];
+
+    // the row of the first step this lane processes, and the update index of the one after it, in flight
+    RecurRow nxt;
+    int ui_n = -1;
+    if (ns > 0) {
+        load_recur_row(p, (size_t)(ns - 1), B, t, nxt);
+        ui_n = p.upd_idx[(size_t)(ns - 1) * B + t];
+    }
+    int st = 0;
+    for (int k = p.Nmax - 1; k >= 0; --k) {
+        if (!__any(k < ns)) continue;  // ragged batch: nobody in this wave has reached its last step yet
+        if (k < ns) {
+            const RecurRow cur = nxt;
+            const bool full = work_row_full(p, k, ui_n, always_full);
+            // x_b, P_b: stored (a quarter of the steps of the bench batch: loaded here, not a row ahead, to keep the
+            // registers of a whole row free), or the prediction itself -- the step was not followed by an update, so row
+            // k + 1 of the filtered history is x^-, P^-, and P_b = P^- + b b^T with b = x^- - x_k
+            double xb[4], Pb[10];
             STE_UNROLL
-            for (int i = 0; i < NP; ++i) load_hist_row(p, (size_t)min((nblk - 1) * NP + i, last_row), B, t, ring[i]);
-        }
-        for (int it = nblk - 1; it >= -1; --it) {
-            const int jb = it + 1;
-            if (jb < nblk) {
+            for (int c = 0; c < 4; ++c) xb[c] = xn[c];
+            {
+                double bv[4];
                 STE_UNROLL
-                for (int i = NP - 1; i >= 0; --i) {
-                    const int k = jb * NP + i;
-                    if (k < ns) {
-                        const HistRow& g = ring[i];
-                        const double* l = slot(jb, i);
-                        double K[4][4], Pb[4][4];
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            STE_UNROLL
-                            for (int c = 0; c < 4; ++c) K[r][c] = l[(r * 4 + c) * 64];
-                        }
-                        int e = 16;
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            STE_UNROLL
-                            for (int c = r; c < 4; ++c) {
-                                const double v = l[(e++) * 64];
-                                Pb[r][c] = v;
-                                Pb[c][r] = v;
-                            }
-                        }
-                        double y[4];
-                        STE_UNROLL
-                        for (int c = 0; c < 4; ++c) y[c] = xs[c] - g.xb[c];
-                        y[3] = wrap180(y[3]);
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            double acc = g.xk[r];
-                            STE_UNROLL
-                            for (int c = 0; c < 4; ++c) acc = fma(K[r][c], y[c], acc);
-                            xs[r] = acc;
-                        }
-                        xs[3] = floored_mod(xs[3], 360.0);
-                        double dP[4][4], KdP[4][4], U[4][4];
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            STE_UNROLL
-                            for (int c = 0; c < 4; ++c) dP[r][c] = Ps[r][c] - Pb[r][c];
-                        }
-                        mm(K, dP, KdP);
-                        mmt_sym(KdP, K, U);
-                        e = 0;
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            STE_UNROLL
-                            for (int c = r; c < 4; ++c) {
-                                const double v = g.Pk[e++] + U[r][c];
-                                Ps[r][c] = v;
-                                Ps[c][r] = v;
-                            }
-                        }
-                        store_vec(p.sm_mean, (size_t)k, B, t, xs);
-                        store_mat(p.sm_cov, (size_t)k, B, t, Ps);
-                    }
-                    // the row this slot holds in the next block; unconditional (clamped) so that no load sits in a branch
-                    const int kl = k - NP;
-                    load_hist_row(p, (size_t)min(max(kl, 0), last_row), B, t, ring[i]);
-                }
-            }
-            __syncthreads();
-        }
-        if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
-    } else {
-        // ---- producers: gains one block ahead ---------------------------------------------------------------------
-        const int i = wave - 1;
-        WorkRow nxt;
-        if (nblk > 0) load_work_row(p, (size_t)min((nblk - 1) * NP + i, last_row), B, t, nxt);
-        for (int it = nblk - 1; it >= -1; --it) {
-            if (it >= 0) {
-                const int k = it * NP + i;
-                const WorkRow cur = nxt;
-                load_work_row(p, (size_t)min(max(k - NP, 0), last_row), B, t, nxt);
-                const bool active = k < ns;
-                double au[10], D[4][4], K[4][4];
-                STE_UNROLL
-                for (int e = 0; e < 10; ++e) {  // idle lanes: the identity, nothing to solve
-                    const bool diag = (e == 0 || e == 4 || e == 7 || e == 9);
-                    au[e] = active ? cur.Pb[e] : (diag ? 1.0 : 0.0);
-                }
-                {
-                    // D = [stored columns 0-1 | columns 2-3 of the filtered covariance] (see kWorkD)
-                    const double c2[4] = {cur.Pc[0], cur.Pc[2], cur.Pc[4], cur.Pc[5]};
-                    const double c3[4] = {cur.Pc[1], cur.Pc[3], cur.Pc[5], cur.Pc[6]};
-                    STE_UNROLL
-                    for (int r = 0; r < 4; ++r) {
-                        D[r][0] = active ? cur.D2[r * 2 + 0] : 0.0;
-                        D[r][1] = active ? cur.D2[r * 2 + 1] : 0.0;
-                        D[r][2] = active ? c2[r] : 0.0;
-                        D[r][3] = active ? c3[r] : 0.0;
-                    }
-                }
-                // K = D pinv(P_b) (unscented.py:333): by factorisation where P_b is safely invertible (then pinv is the
-                // inverse), by the eigenvalue route -- with NumPy's rank cutoff -- for the lanes where it is not
-                const bool bad = kEigGains ? true : ldl_right_solve4(au, D, K);
-                if (__any(bad)) {
-                    double Pb[4][4], Pbi[4][4], K2[4][4];
-                    int e = 0;
-                    STE_UNROLL
-                    for (int r = 0; r < 4; ++r) {
-                        STE_UNROLL
-                        for (int c = r; c < 4; ++c) {
-                            Pb[r][c] = au[e];
-                            Pb[c][r] = au[e];
-                            ++e;
-                        }
-                    }
-                    const int pst = sym_pinv4(Pb, Pbi);
-                    mm(D, Pbi, K2);
-                    if (bad) {
-                        if (active) st |= pst;
-                        STE_UNROLL
-                        for (int r = 0; r < 4; ++r) {
-                            STE_UNROLL
-                            for (int c = 0; c < 4; ++c) K[r][c] = K2[r][c];
-                        }
-                    }
-                }
-                double* l = slot(it, i);
+                for (int c = 0; c < 4; ++c) bv[c] = xn[c] - cur.xk[c];
                 STE_UNROLL
                 for (int r = 0; r < 4; ++r) {
                     STE_UNROLL
-                    for (int c = 0; c < 4; ++c) l[(r * 4 + c) * 64] = K[r][c];
+                    for (int c = r; c < 4; ++c) Pb[tix(r, c)] = fma(bv[r], bv[c], Pn[tix(r, c)]);
                 }
-                STE_UNROLL
-                for (int q = 0; q < 10; ++q) l[(16 + q) * 64] = cur.Pb[q];
             }
-            __syncthreads();
+            if (full) {
+                const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) xb[c] = w[(kWorkXb + c) * B];
+                STE_UNROLL
+                for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
+            }
+            {
+                const int kn = clampk(k - 1);
+                load_recur_row(p, (size_t)kn, B, t, nxt);
+                ui_n = p.upd_idx[(size_t)kn * B + t];
+            }
+            double y[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) y[c] = xs[c] - xb[c];
+            y[3] = wrap180(y[3]);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                double acc = cur.xk[r];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) acc = fma(cur.K[r * 4 + c], y[c], acc);
+                xs[r] = acc;
+            }
+            xs[3] = floored_mod(xs[3], 360.0);
+            // P^s_k = P_k + K (P^s_{k+1} - P_b) K^T, symmetric operands packed
+            double dP[10];
+            STE_UNROLL
+            for (int e = 0; e < 10; ++e) dP[e] = Ps[e] - Pb[e];
+            double KdP[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) {
+                    double acc = cur.K[r * 4 + 0] * dP[tix(0, c)];
+                    STE_UNROLL
+                    for (int i = 1; i < 4; ++i) acc = fma(cur.K[r * 4 + i], dP[tix(i, c)], acc);
+                    KdP[r][c] = acc;
+                }
+            }
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = r; c < 4; ++c) {
+                    double acc = KdP[r][0] * cur.K[c * 4 + 0];
+                    STE_UNROLL
+                    for (int i = 1; i < 4; ++i) acc = fma(KdP[r][i], cur.K[c * 4 + i], acc);
+                    Ps[tix(r, c)] = cur.Pk[tix(r, c)] + acc;
+                }
+            }
+            store_vec(p.sm_mean, (size_t)k, B, t, xs);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) st_stream(&p.sm_cov[((size_t)k * 16 + r * 4 + c) * B + t], Ps[tix(r, c)]);
+            }
+            // row k becomes "row k + 1" of the next step
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) xn[c] = cur.xk[c];
+            STE_UNROLL
+            for (int e = 0; e < 10; ++e) Pn[e] = cur.Pk[e];
         }
     }
-    if (st && valid) atomicOr(&p.status[t], st);
+    double chk = 0.0;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) chk += xs[c] * 0.0;
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) chk += Ps[e] * 0.0;
+    if (!(chk == 0.0)) st |= STE_STATUS_NAN;
+    if (st) atomicOr(&p.status[t], st);
 }
 
 
@@ -1366,8 +1478,7 @@ __global__ __launch_bounds__(64) void predict_kernel(size_t count, const Mats m,
     double xi[4], Pi[4][4];
     load_vec(x, 0, count, i, xi);
     load_mat(P, 0, count, i, Pi);
-    EigBasis c0, c1;
-    int st = ukf_predict<false, false>(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i, nullptr, nullptr, c0, c1);
+    int st = ukf_predict(m, xi, Pi, dt[i], sr[i], cr[i], noise, 0, count, i);
     if (!all_finite(xi, Pi)) st |= STE_STATUS_NAN;
     store_vec(x_out, 0, count, i, xi);
     store_mat(P_out, 0, count, i, Pi);
@@ -1480,6 +1591,19 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     memcpy(kp->m.R, b->R, sizeof(double) * 16);
     kp->m.chi_alpha = b->chi_alpha;
     kp->m.robust_iters = (b->flags & STE_FLAG_ROBUST) ? (b->robust_max_iter > 0 ? b->robust_max_iter : 50) : 0;
+    // The sigma weights sum to one for every weight0 the reference accepts (unscented.py:125-132: wi = (1 - w0) / 2n);
+    // the streamed moments of the forward kernels rely on it.
+    if (!(fabs(b->w0 + 8.0 * b->wi - 1.0) <= 1e-14))
+        return fail(STE_EINVAL, "sigma weights must sum to one: w0 + 2 n wi = 1 (unscented.py:125-132)");
+    {
+        bool sel = kp->m.robust_iters == 0;
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                sel = sel && b->H[r * 4 + c] == ((r == c && r < 2) ? 1.0 : 0.0);
+                if (r >= 2 || c >= 2) sel = sel && b->R[r * 4 + c] == 0.0;
+            }
+        kp->fast_upd = sel && b->R[1] == b->R[4];
+    }
     kp->nsteps = b->nsteps;
     kp->x0 = b->x0;
     kp->P0 = b->P0;
@@ -1498,13 +1622,8 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_mean = b->sm_mean;
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
-    // gains can be shared between the passes only when both use the same rates (see ukf_predict<kGains>) and when the
-    // caller's sigma-fan constants satisfy the two identities the compact work rows are built on: weights that sum to
-    // one (P_b from the predicted covariance) and 2 wi fan_scale = 1 (D[:, 2:4] = P_k[:, 2:4]).  unscented.py:95,125,132
-    // give both once compute_weights has run; a fan drawn before that (scale = n, HostBatch.weights_computed = False)
-    // does not, and then the smoother recomputes everything.
-    const bool identities = fabs(2.0 * b->wi * b->fan_scale - 1.0) <= 1e-14 && fabs(b->w0 + 8.0 * b->wi - 1.0) <= 1e-14;
-    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts || !identities) ? nullptr : b->rts_work;
+    // the forward pass can form the smoother's gains only when both passes use the same rates (see kWorkK)
+    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts) ? nullptr : b->rts_work;
     return STE_OK;
 }
 
@@ -1526,37 +1645,27 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
         return check_hip(hipGetLastError(), "ukf_forward_q4 launch");
     }
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
-    if (kp.rts_work)
-        hipLaunchKernelGGL(ste::ukf_forward_l1<true>, dim3(grid), dim3(64), 0, s, kp);
-    else
-        hipLaunchKernelGGL(ste::ukf_forward_l1<false>, dim3(grid), dim3(64), 0, s, kp);
+    if (kp.fast_upd) {
+        if (kp.rts_work)
+            hipLaunchKernelGGL((ste::ukf_forward_l1<true, true>), dim3(grid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL((ste::ukf_forward_l1<false, true>), dim3(grid), dim3(64), 0, s, kp);
+    } else {
+        if (kp.rts_work)
+            hipLaunchKernelGGL((ste::ukf_forward_l1<true, false>), dim3(grid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL((ste::ukf_forward_l1<false, false>), dim3(grid), dim3(64), 0, s, kp);
+    }
     return check_hip(hipGetLastError(), "ukf_forward launch");
-}
-
-// Shape of the smoother workgroup: producer waves per consumer wave (tuning & 0xff) and whether every gain goes the
-// eigenvalue route (tuning & 0x100) instead of only the ones whose P_b is close to singular.
-template <int NP>
-void launch_smooth(const ste::KParams& kp, unsigned grid, hipStream_t s) {
-    if (kp.tuning & 0x100)
-        hipLaunchKernelGGL((ste::urtss_smooth_wg<NP, true>), dim3(grid), dim3((NP + 1) * 64), 0, s, kp);
-    else
-        hipLaunchKernelGGL((ste::urtss_smooth_wg<NP, false>), dim3(grid), dim3((NP + 1) * 64), 0, s, kp);
 }
 
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
     if (kp.rts_work) {
-        switch (kp.tuning & 0xff) {
-            case 1: launch_smooth<1>(kp, grid, s); break;
-            case 2: launch_smooth<2>(kp, grid, s); break;
-            case 4: launch_smooth<4>(kp, grid, s); break;
-            default: launch_smooth<3>(kp, grid, s); break;
-        }
-        int rc = check_hip(hipGetLastError(), "urtss_smooth_wg launch");
-        if (rc) return rc;
-        hipLaunchKernelGGL(ste::urtss_backward_l1<true>, dim3(grid), dim3(64), 0, s, kp);
-    } else
-        hipLaunchKernelGGL(ste::urtss_backward_l1<false>, dim3(grid), dim3(64), 0, s, kp);
+        hipLaunchKernelGGL(ste::urtss_recur_l1, dim3(grid), dim3(64), 0, s, kp);
+        return check_hip(hipGetLastError(), "urtss_recur launch");
+    }
+    hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);
     return check_hip(hipGetLastError(), "urtss_backward launch");
 }
 
@@ -1565,6 +1674,17 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
 extern "C" {
 
 int ste_version(void) { return STE_VERSION; }
+
+#ifdef STE_DEBUG_SWEEPS
+int ste_dbg_counters(unsigned long long* out, int reset) {  // developer instrumentation, not part of the ABI
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ste::g_dbg), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ste::g_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 const char* ste_last_error(void) { return g_err; }
 

@@ -632,38 +632,64 @@ __device__ __forceinline__ double rcp_refined(double d) {
 // falls under 1e-15 of the largest, and both routes are backward stable, so they agree to ~cond(A) * 2^-52.  Returns
 // true ("bad") when a pivot is not safely away from zero (or anything is NaN): the caller then takes the eigenvalue
 // route, which also reproduces pinv's rank decisions.
-constexpr double kLdlPivotTol = 1e-9;
-__device__ __forceinline__ bool ldl_right_solve4(const double (&au)[10], const double (&D)[4][4], double (&K)[4][4]) {
+// Pivot threshold: with pivots no smaller than 1e-7 of the largest diagonal entry cond(A) stays under ~1e7 and the gain
+// agrees with pinv's to ~1e-9, three decades inside the 1e-6 parity bound (round 2 used 1e-9: 2e-7 at worst, too close).
+constexpr double kLdlPivotTol = 1e-7;
+// The factorisation: L (unit lower, l10 l20 l30 l21 l31 l32), the reciprocal pivots, and the "bad" verdict.
+struct Ldl4 {
+    double l10, l20, l30, l21, l31, l32, i0, i1, i2, i3;
+    bool bad;
+};
+__device__ __forceinline__ void ldl_factor4(const double (&au)[10], Ldl4& f) {
     const double a00 = au[0], a01 = au[1], a02 = au[2], a03 = au[3], a11 = au[4], a12 = au[5], a13 = au[6], a22 = au[7],
                  a23 = au[8], a33 = au[9];
     const double scale = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fabs(a33)));
-    const double d0 = a00, i0 = rcp_refined(d0);
-    const double l10 = a01 * i0, l20 = a02 * i0, l30 = a03 * i0;
-    const double d1 = fma(-l10, a01, a11), i1 = rcp_refined(d1);
-    const double t21 = fma(-l20, a01, a12), t31 = fma(-l30, a01, a13);
-    const double l21 = t21 * i1, l31 = t31 * i1;
-    const double d2 = fma(-l21, t21, fma(-l20, a02, a22)), i2 = rcp_refined(d2);
-    const double t32 = fma(-l31, t21, fma(-l30, a02, a23));
-    const double l32 = t32 * i2;
-    const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a03, a33))), i3 = rcp_refined(d3);
+    const double d0 = a00;
+    f.i0 = rcp_refined(d0);
+    f.l10 = a01 * f.i0;
+    f.l20 = a02 * f.i0;
+    f.l30 = a03 * f.i0;
+    const double d1 = fma(-f.l10, a01, a11);
+    f.i1 = rcp_refined(d1);
+    const double t21 = fma(-f.l20, a01, a12), t31 = fma(-f.l30, a01, a13);
+    f.l21 = t21 * f.i1;
+    f.l31 = t31 * f.i1;
+    const double d2 = fma(-f.l21, t21, fma(-f.l20, a02, a22));
+    f.i2 = rcp_refined(d2);
+    const double t32 = fma(-f.l31, t21, fma(-f.l30, a02, a23));
+    f.l32 = t32 * f.i2;
+    const double d3 = fma(-f.l32, t32, fma(-f.l31, t31, fma(-f.l30, a03, a33)));
+    f.i3 = rcp_refined(d3);
     const double dmin = fmin(fmin(fabs(d0), fabs(d1)), fmin(fabs(d2), fabs(d3)));
-    const bool bad = !(dmin > kLdlPivotTol * scale);  // also true for NaN anywhere
+    f.bad = !(dmin > kLdlPivotTol * scale);  // also true for NaN anywhere
+}
+// k = (row of D) A^-1, i.e. A k^T = (row of D)^T
+__device__ __forceinline__ void ldl_solve_row4(const Ldl4& f, const double (&d)[4], double (&k)[4]) {
+    const double y0 = d[0];
+    const double y1 = fma(-f.l10, y0, d[1]);
+    const double y2 = fma(-f.l21, y1, fma(-f.l20, y0, d[2]));
+    const double y3 = fma(-f.l32, y2, fma(-f.l31, y1, fma(-f.l30, y0, d[3])));
+    const double x3 = y3 * f.i3;
+    const double x2 = fma(-f.l32, x3, y2 * f.i2);
+    const double x1 = fma(-f.l31, x3, fma(-f.l21, x2, y1 * f.i1));
+    const double x0 = fma(-f.l30, x3, fma(-f.l20, x2, fma(-f.l10, x1, y0 * f.i0)));
+    k[0] = x0;
+    k[1] = x1;
+    k[2] = x2;
+    k[3] = x3;
+}
+__device__ __forceinline__ bool ldl_right_solve4(const double (&au)[10], const double (&D)[4][4], double (&K)[4][4]) {
+    Ldl4 f;
+    ldl_factor4(au, f);
     STE_UNROLL
-    for (int r = 0; r < 4; ++r) {  // row r of K solves A k = (row r of D)^T
-        const double y0 = D[r][0];
-        const double y1 = fma(-l10, y0, D[r][1]);
-        const double y2 = fma(-l21, y1, fma(-l20, y0, D[r][2]));
-        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, D[r][3])));
-        const double x3 = y3 * i3;
-        const double x2 = fma(-l32, x3, y2 * i2);
-        const double x1 = fma(-l31, x3, fma(-l21, x2, y1 * i1));
-        const double x0 = fma(-l30, x3, fma(-l20, x2, fma(-l10, x1, y0 * i0)));
-        K[r][0] = x0;
-        K[r][1] = x1;
-        K[r][2] = x2;
-        K[r][3] = x3;
-    }
-    return bad;
+    for (int r = 0; r < 4; ++r) ldl_solve_row4(f, D[r], K[r]);
+    return f.bad;
+}
+__device__ __forceinline__ bool ldl_right_solve_row(const double (&au)[10], const double (&d)[4], double (&k)[4]) {
+    Ldl4 f;
+    ldl_factor4(au, f);
+    ldl_solve_row4(f, d, k);
+    return f.bad;
 }
 
 // C = A * B (4x4)

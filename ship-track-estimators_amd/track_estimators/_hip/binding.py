@@ -20,7 +20,7 @@ STE_FLAG_ROBUST = 0x4
 STE_FLAG_LANES_1 = 0x10
 STE_FLAG_LANES_4 = 0x20
 
-STE_RTS_WORK_ROWS = 22  # doubles per (step, track) of ste_ukf_batch_f64.rts_work
+STE_RTS_WORK_ROWS = 30  # doubles per (step, track) of ste_ukf_batch_f64.rts_work
 
 STE_STATUS_NAN = 0x1
 STE_STATUS_CLAMPED = 0x2

@@ -446,7 +446,8 @@ class SmootherPipeline:
     """
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
-                 forward_streams: Optional[int] = None, smoother_streams: int = 2, forward_lanes: int = 1):
+                 forward_streams: Optional[int] = None, smoother_streams: int = 2, forward_lanes: int = 1,
+                 shared: bool = False):
         import torch
 
         self.torch = torch
@@ -457,6 +458,13 @@ class SmootherPipeline:
         self.forward_lanes = int(forward_lanes)
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
         quad = forward_lanes == 4 or (forward_lanes == 0 and (ntracks or 10_000) <= 32_768)
+        self.shared = bool(shared)
+        if shared:
+            # no partition: forward passes and smoothers on streams that each own a hardware queue but may use every CU.
+            # A lane-per-track forward wave holds 264 registers (one per SIMD by construction), a smoother wave 232, so
+            # the smoother of one batch slots in beside the forward waves of the next ones and takes the issue slots they
+            # leave (its waves mostly wait for memory).
+            forward_cus = ncu
         if forward_cus is None:
             # The smoother moves ~450 B per track-step at ~28 GB/s per CU whatever the partition size (~90 CU-ms per
             # 10 000 x 500 batch) and needs its workgroups (two per CU) in one round.  A lane-per-track forward pass costs
@@ -474,12 +482,12 @@ class SmootherPipeline:
             nt = ntracks or 10_000
             waves = -(-nt * 4 // 64) if quad else -(-nt // 64)
             slots = forward_cus * (8 if quad else 4)
-            forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(6, (2 * slots + waves) // (2 * waves)))
-        if not (0 < forward_cus < ncu):
+            forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(8, (2 * slots + waves) // (2 * waves)))
+        if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
             raise ValueError("forward_streams and smoother_streams must be >= 1")
-        self.forward_cus, self.smoother_cus = int(forward_cus), int(ncu - forward_cus)
+        self.forward_cus, self.smoother_cus = int(forward_cus), int(ncu if shared else ncu - forward_cus)
         self._raw = []
         self.fwd_streams, self.bwd_streams = [], []
         # unrestricted stream for the smoother of the last batch of a sequence; created here, not at first use, so
@@ -491,7 +499,8 @@ class SmootherPipeline:
         try:
             with torch.cuda.device(self.device):
                 for first, count, n, out in ((0, self.forward_cus, forward_streams, self.fwd_streams),
-                                             (self.forward_cus, self.smoother_cus, smoother_streams, self.bwd_streams)):
+                                             (0 if shared else self.forward_cus, self.smoother_cus, smoother_streams,
+                                              self.bwd_streams)):
                     for _ in range(n):
                         h = C.c_void_p()
                         binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)),

@@ -25,10 +25,11 @@ def _uniform(B, nobs, s, seed0):
 
 
 @pytest.mark.gpu
-def test_fan_constants_off_the_identities_take_the_standalone_smoother():
-    """The compact work rows assume weights that sum to one and 2 wi fan_scale = 1.  A fan drawn with scale = n
-    (weights_computed = False: fan_scale 4, wi 1/6) breaks the second, so the library must not use the rows: the fused
-    call has to return the bits of the stand-alone smoother, and differ from the run with the regular constants."""
+def test_fan_constants_off_their_usual_relation_still_smooth_right():
+    """A fan drawn with scale = n (weights_computed = False: fan_scale 4, wi 1/6, so 2 wi fan_scale = 4/3) is another
+    filter than the regular one; the work rows of round 2 silently assumed 2 wi fan_scale = 1 (columns 2-3 of D taken
+    from the filtered covariance) and smoothed such a batch wrongly.  The forward pass now forms D from the fan itself:
+    the smoother from its rows must agree with the stand-alone smoother, which recomputes everything."""
     import torch
     from track_estimators import batch
 
@@ -39,13 +40,34 @@ def test_fan_constants_off_the_identities_take_the_standalone_smoother():
         db = batch.DeviceBatch(hb, fuse_gains=fuse)
         db.run()
         torch.cuda.synchronize()
-        res.append((db.sm_mean.clone(), db.sm_cov.clone(), db.fwd_mean.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert not db.status_host().any()
+        res.append(db.smoothed() + (db.fwd_mean.clone(),))
+    assert mean_err(res[0][0], res[1][0]) < 1e-9 and cov_err(res[0][1], res[1][1]) < 1e-9
     hb.weights_computed = True
     db = batch.DeviceBatch(hb)
     db.run()
     torch.cuda.synchronize()
     assert float((db.fwd_mean - res[0][2]).abs().max()) > 1e-6  # the other scale really is another filter
+
+
+def test_abi_refuses_weights_that_do_not_sum_to_one():
+    """w0 + 2 n wi = 1 for every weight0 the reference accepts (unscented.py:125-132); the streamed moments rely on it, so
+    anything else is an argument error, not a silently different filter.  (Argument validation only: runs without a GPU.)"""
+    import ctypes as C
+
+    from track_estimators._hip import binding
+
+    lib = binding.load()
+    s = binding.SteUkfBatchF64()
+    s.B, s.Nmax, s.Tmax, s.n = 1, 0, 1, 4
+    s.fan_scale, s.w0, s.wi = 3.0, -1.0 / 3.0, 0.2
+    eye = (C.c_double * 16)(*([1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0]))
+    s.H = s.Q = s.R = C.addressof(eye)
+    fake = 4096  # never dereferenced: the call must fail before any launch
+    for f in ("x0", "P0", "z", "fwd_mean", "fwd_cov", "status"):
+        setattr(s, f, fake)
+    rc = lib.ste_ukf_forward_f64(C.byref(s), None)
+    assert rc == -1 and b"sum to one" in lib.ste_last_error()
 
 
 @pytest.mark.gpu
