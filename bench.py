@@ -214,7 +214,8 @@ def _main(stack):
     ap.add_argument("--forward-streams", type=int, default=None)
     ap.add_argument("--smoother-streams", type=int, default=None)
     ap.add_argument("--forward-lanes", type=int, default=None, help="lane mapping of the pipelined forward passes (1, 4, 0)")
-    ap.add_argument("--shared", action="store_true", help="no CU partition: forward passes and smoothers share every CU")
+    ap.add_argument("--partition", action="store_true",
+                    help="round-2 pipeline: forward passes and smoothers on disjoint CU partitions (default: they share every CU)")
     ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
     ap.add_argument("--no-gp", action="store_true",
                     help="skip the `extra.gp_config4` entry (BASELINE configs[4]: one batched GP objective at 1000 x 2000, "
@@ -283,7 +284,7 @@ def _main(stack):
         try:
             kw = {k: v for k, v in (("forward_cus", args.forward_cus), ("forward_streams", args.forward_streams),
                                     ("smoother_streams", args.smoother_streams),
-                                    ("forward_lanes", args.forward_lanes), ("shared", args.shared or None)) if v is not None}
+                                    ("forward_lanes", args.forward_lanes), ("shared", False if args.partition else None)) if v is not None}
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
@@ -425,9 +426,12 @@ def _main(stack):
                 "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (", RCCL all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
-                             f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight on {pipe.forward_cus} CUs beside "
-                             f"{len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, "
-                             f"{len(dbs)} sets of histories in rotation)"),
+                             f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
+                             + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing the {pipe.forward_cus} CUs "
+                                "(one forward wave per SIMD by construction, smoother waves beside them; one hardware queue per stream, "
+                                if pipe.shared else
+                                f"on {pipe.forward_cus} CUs beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, ")
+                             + f"{len(dbs)} sets of histories in rotation)"),
                 "lanes_per_track": args.lanes, "tuning": args.tuning, "untimed_prepass_steps": prepass,
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},

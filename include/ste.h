@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 300 /* 0.3.0: rts_work rows hold the smoother gain (30 doubles); sigma weights must sum to one */
+#define STE_VERSION 300 /* 0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma weights must sum to one */
 
 /* error codes */
 #define STE_OK 0
@@ -56,10 +56,13 @@ extern "C" {
 #define STE_FLAG_NO_INITIAL_UPDATE 0x2u /* skip the update with z[:,0] that run() performs before the first predict */
 #define STE_FLAG_LANES_1 0x10u /* forward pass with one lane per track for this call (default: chosen by batch size) */
 #define STE_FLAG_LANES_4 0x20u /* forward pass with one DPP quad (4 lanes) per track for this call */
+#define STE_FLAG_PACKED_COV 0x40u /* fwd_cov and sm_cov hold upper triangles, [Nmax+1][10][B] (row-major: 00 01 02 03 11 12 13
+                                     22 23 33), instead of full matrices [Nmax+1][16][B]: the covariances are symmetric by
+                                     construction, and 96 of the 828 bytes the two passes move per track-step go */
 #define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
                                 the reference ships with its call site commented out, :228) */
 
-#define STE_RTS_WORK_ROWS 30 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work */
+#define STE_RTS_WORK_ROWS 30 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work (+ B doubles at its end) */
 
 /* status[] bits (per track) */
 #define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
@@ -115,20 +118,23 @@ typedef struct ste_ukf_batch_f64 {
 
     /* outputs (device) */
     double* fwd_mean; /* [Nmax+1][4][B]  row 0 = prior (kalman_filter.py:76) */
-    double* fwd_cov;  /* [Nmax+1][16][B] */
+    double* fwd_cov;  /* [Nmax+1][16][B]; [Nmax+1][10][B] with STE_FLAG_PACKED_COV */
     double* sm_mean;  /* [Nmax+1][4][B]  smoothed; row nsteps = filtered row nsteps */
-    double* sm_cov;   /* [Nmax+1][16][B] */
+    double* sm_cov;   /* [Nmax+1][16][B]; [Nmax+1][10][B] with STE_FLAG_PACKED_COV */
     int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
 
     /*
-     * Optional workspace [Nmax][STE_RTS_WORK_ROWS][B] (device), caller-owned.  When it is non-NULL and sog_rate_rts ==
-     * cog_rate_rts == NULL, ste_ukf_forward_f64 also evaluates what the smoother's step k needs of the sigma fan of the
-     * filtered state of step k (unscented.py:297-333: back-prediction x_b, P_b, cross-covariance D) while it has that fan
-     * in registers, forms the gain K = D pinv(P_b) (:333) and stores it here (row k: K 16 | x_b 4 | P_b upper triangle 10;
-     * x_b and P_b only for the steps where they do not follow from rows k and k + 1 of the filtered history, i.e. steps
-     * followed by an update, row 0 of a run that starts with one, runs with recorded noise).  ste_urtss_backward_f64 on
-     * the same batch is then the recurrence of :337-349 alone; it only reads the workspace, so it may be called again on
-     * the same forward result.  Results are those of the stand-alone smoother to rounding.
+     * Optional workspace of (Nmax * STE_RTS_WORK_ROWS + 1) * B doubles (device), caller-owned.  When it is non-NULL and
+     * sog_rate_rts == cog_rate_rts == NULL, ste_ukf_forward_f64 also evaluates what the smoother's step k needs of the sigma
+     * fan of the filtered state of step k (unscented.py:297-330: back-prediction x_b, P_b, cross-covariance D) while it has
+     * that fan in registers, and stores it here: row k = columns 0-1 of D (8) | x_b (4) | P_b upper triangle (10) |
+     * columns 2-3 of D (8), each [B].  x_b and P_b are written only for the steps where they do not follow from rows k and
+     * k + 1 of the filtered history (steps followed by an update, row 0 of a run that starts with one, runs with recorded
+     * noise); columns 2-3 of D only at and after a track's first clamped / unconverged square root (elsewhere they are
+     * 2 wi fan_scale times columns 2-3 of the filtered covariance); the last B words hold that step index per track.
+     * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) and runs the recurrence
+     * (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Results are those
+     * of the stand-alone smoother to rounding.
      * NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history was not
      * produced by ste_ukf_forward_f64 on this batch).
      */

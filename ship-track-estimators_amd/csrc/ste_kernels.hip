@@ -57,16 +57,23 @@ struct KParams {
 
 constexpr int kColdEvery = 64;  // power of two
 
-// rts_work row layout (round 3): K (16, row-major) | x_b (4) | P_b upper triangle, row-major (10).
-// The forward kernels form the smoother's gain K = D pinv(P_b) themselves (unscented.py:297-333: the smoother's step k starts
-// from the same filtered state as the forward predict of step k, with the same dt and rates, so its fan, its back-
-// prediction x_b, its P_b and its cross-covariance D are values the predict already holds), which leaves the backward pass
-// a pure recurrence (unscented.py:337-349).  x_b and P_b, which the recurrence needs as well, are written only for the
-// steps where they cannot be rebuilt from the filtered history -- steps followed by a measurement update, row 0 when the
-// run starts with an update, and every step of a run with recorded noise; elsewhere x_b = fwd_mean[k + 1] and
-// P_b = fwd_cov[k + 1] + b b^T with b = fwd_mean[k + 1] - fwd_mean[k].
-constexpr int kWorkK = 0, kWorkXb = 16, kWorkPb = 20, kWorkElems = STE_RTS_WORK_ROWS;
+// rts_work row layout (round 3): columns 0-1 of D, row-major 4 x 2 (8) | x_b (4) | P_b upper triangle, row-major (10) |
+// columns 2-3 of D, row-major 4 x 2 (8).
+// The smoother's step k (unscented.py:297-333) starts from the same filtered state as the forward predict of step k, with
+// the same dt and rates, so its fan, its back-prediction x_b, its P_b and its cross-covariance D are values the predict
+// already holds: the forward kernels leave them here and the backward pass is the gain solve K = D pinv(P_b) (:333) plus
+// the recurrence (:337-349).  What is written is only what cannot be had cheaper:
+//   * x_b and P_b only for the steps where they do not follow from the filtered history -- steps followed by a
+//     measurement update, row 0 when the run starts with an update, every step of a run with recorded noise; elsewhere
+//     x_b = fwd_mean[k + 1] and P_b = fwd_cov[k + 1] + b b^T with b = fwd_mean[k + 1] - fwd_mean[k];
+//   * columns 2-3 of D only at and after a track's first clamped / unconverged square root: speed and heading pass
+//     through the process model with unit slope (non_linear_process.py:74-75), so D[:, 2:4] = 2 wi (T T)[:, 2:4], which for
+//     an exact T = sqrtm(scale P_k) is (2 wi scale) P_k[:, 2:4] -- the filtered covariance the smoother reads anyway.
+//     The step index of that first bad square root is kept, as a double, in the B words that follow the Nmax rows
+//     (kNeverBad when there is none): the smoother never looks at status[], one kernel smooths every track.
+constexpr int kWorkD = 0, kWorkXb = 8, kWorkPb = 12, kWorkD23 = 22, kWorkElems = STE_RTS_WORK_ROWS;
 static_assert(kWorkElems == 30, "include/ste.h: STE_RTS_WORK_ROWS");
+constexpr double kNeverBad = 1e300;
 
 __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t B, size_t t, double (&M)[4][4]) {
     STE_UNROLL
@@ -91,6 +98,61 @@ __device__ __forceinline__ void load_vec(const double* base, size_t row, size_t 
 __device__ __forceinline__ void store_vec(double* base, size_t row, size_t B, size_t t, const double (&v)[4]) {
     STE_UNROLL
     for (int c = 0; c < 4; ++c) st_stream(&base[(row * 4 + c) * B + t], v[c]);
+}
+
+// Covariance histories (fwd_cov, sm_cov) come in two layouts: [row][16][B] full 4 x 4 matrices, the reference's return
+// shape, or -- STE_FLAG_PACKED_COV -- [row][10][B] upper triangles (row-major: 00 01 02 03 11 12 13 22 23 33).  The
+// matrices are symmetric by construction, so the packed form loses nothing; it takes 48 of 128 bytes off every history
+// row written and lets the host expand on its way out (DeviceBatch.download).
+__device__ __forceinline__ size_t cov_at(bool packed, size_t row, int r, int c) {  // r <= c
+    return packed ? row * 10 + (size_t)(r * 4 - (r * (r - 1)) / 2 + (c - r)) : row * 16 + (size_t)(r * 4 + c);
+}
+// packed symmetric -> history row
+__device__ __forceinline__ void store_cov_p(double* base, bool packed, size_t row, size_t B, size_t t, const double (&P)[10]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) st_stream(&base[cov_at(packed, row, r, c) * B + t], P[tix(r, c)]);
+    }
+    if (!packed) {
+        STE_UNROLL
+        for (int r = 1; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < r; ++c) st_stream(&base[(row * 16 + r * 4 + c) * B + t], P[tix(r, c)]);
+        }
+    }
+}
+__device__ __forceinline__ void load_cov_p(const double* base, bool packed, size_t row, size_t B, size_t t, double (&P)[10]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) P[tix(r, c)] = base[cov_at(packed, row, r, c) * B + t];
+    }
+}
+// full 4 x 4 <-> history row (the literal kernels); the packed layout keeps the upper triangle
+__device__ __forceinline__ void store_cov_m(double* base, bool packed, size_t row, size_t B, size_t t, const double (&M)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            if (c >= r)
+                st_stream(&base[cov_at(packed, row, r, c) * B + t], M[r][c]);
+            else if (!packed)
+                st_stream(&base[(row * 16 + r * 4 + c) * B + t], M[r][c]);
+        }
+    }
+}
+__device__ __forceinline__ void load_cov_m(const double* base, bool packed, size_t row, size_t B, size_t t, double (&M)[4][4]) {
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            if (packed)
+                M[r][c] = base[cov_at(true, row, r < c ? r : c, r < c ? c : r) * B + t];
+            else
+                M[r][c] = base[(row * 16 + r * 4 + c) * B + t];
+        }
+    }
 }
 
 __device__ __forceinline__ bool all_finite(const double (&x)[4], const double (&P)[4][4]) {
@@ -474,13 +536,14 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
 // forward pass, one lane per track (ste_lane.h)
 // ---------------------------------------------------------------------------------------------------------------
 // UKF predict (unscented.py:178-207) on packed (x, P), the sigma pairs streamed through running moments; with `work` it
-// also leaves the smoother's row of this step (see kWorkK).  x, P are replaced by the predicted mean (+ recorded noise)
-// and covariance.
+// also leaves the smoother's row of this step (see kWorkD).  x, P are replaced by the predicted mean (+ recorded noise)
+// and covariance.  `flagged` is sticky: set once a square root of this track was clamped or did not converge; from that
+// step on columns 2-3 of D are stored as well.
 template <bool kGains>
 __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], double (&P)[10], double (&V)[4][4], bool warm,
                                             double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, size_t nrow, size_t B, size_t t, double* work,
-                                            bool full_row, bool all_eig) {
+                                            bool full_row, bool& flagged, double* first_bad) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double T[10];
     const int st = sym_sqrt_p(P, p.fan_scale, T, V, warm);
@@ -544,28 +607,32 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
     Pn[tix(2, 2)] = two_wi * f.S[tix(2, 2)];
     Pn[tix(2, 3)] = two_wi * f.S[tix(2, 3)];
     Pn[tix(3, 3)] = two_wi * f.S[tix(3, 3)];
-    // The smoother's cross-covariance D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T (the centre's deviation from x_k is zero
-    // and x_b cancels in the difference), while the moments are at hand: rows 2-3 of its columns 0-1 are the cross moments
-    // S[c][2], S[c][3] just formed (Pn before Q is added); speed and heading pass through the process model with unit
-    // slope, so its columns 2-3 are 2 wi (T T)[:, 2:4].
-    double D[4][4];
     if (kGains && work) {
-        D[0][0] = p.wi * f.Dn[0][0];
-        D[0][1] = p.wi * f.Dn[0][1];
-        D[1][0] = p.wi * f.Dn[1][0];
-        D[1][1] = p.wi * f.Dn[1][1];
-        D[2][0] = Pn[tix(0, 2)];
-        D[2][1] = Pn[tix(1, 2)];
-        D[3][0] = Pn[tix(0, 3)];
-        D[3][1] = Pn[tix(1, 3)];
-        D[0][2] = two_wi * f.TT[0][0];
-        D[0][3] = two_wi * f.TT[0][1];
-        D[1][2] = two_wi * f.TT[1][0];
-        D[1][3] = two_wi * f.TT[1][1];
-        D[2][2] = Pn[tix(2, 2)];
-        D[2][3] = Pn[tix(2, 3)];
-        D[3][2] = Pn[tix(2, 3)];
-        D[3][3] = Pn[tix(3, 3)];
+        // The smoother's cross-covariance D = wi sum_i T_i (chi'_{i+} - chi'_{i-})^T (the centre's deviation from x_k is
+        // zero and x_b cancels in the difference): rows 2-3 of its columns 0-1 are the cross moments S[c][2], S[c][3] just
+        // formed, i.e. Pn before Q is added.
+        double* w = work + (nrow * kWorkElems) * B + t;
+        st_stream(&w[(kWorkD + 0) * B], p.wi * f.Dn[0][0]);
+        st_stream(&w[(kWorkD + 1) * B], p.wi * f.Dn[0][1]);
+        st_stream(&w[(kWorkD + 2) * B], p.wi * f.Dn[1][0]);
+        st_stream(&w[(kWorkD + 3) * B], p.wi * f.Dn[1][1]);
+        st_stream(&w[(kWorkD + 4) * B], Pn[tix(0, 2)]);
+        st_stream(&w[(kWorkD + 5) * B], Pn[tix(1, 2)]);
+        st_stream(&w[(kWorkD + 6) * B], Pn[tix(0, 3)]);
+        st_stream(&w[(kWorkD + 7) * B], Pn[tix(1, 3)]);
+        const bool bad_now = (st & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
+        if (bad_now && !flagged) *first_bad = (double)nrow;
+        flagged = flagged || bad_now;
+        if (flagged) {  // columns 2-3 of D = 2 wi (T T)[:, 2:4]: (2 wi scale) P_k[:, 2:4] only for an exact square root
+            st_stream(&w[(kWorkD23 + 0) * B], two_wi * f.TT[0][0]);
+            st_stream(&w[(kWorkD23 + 1) * B], two_wi * f.TT[0][1]);
+            st_stream(&w[(kWorkD23 + 2) * B], two_wi * f.TT[1][0]);
+            st_stream(&w[(kWorkD23 + 3) * B], two_wi * f.TT[1][1]);
+            st_stream(&w[(kWorkD23 + 4) * B], Pn[tix(2, 2)]);
+            st_stream(&w[(kWorkD23 + 5) * B], Pn[tix(2, 3)]);
+            st_stream(&w[(kWorkD23 + 6) * B], Pn[tix(2, 3)]);
+            st_stream(&w[(kWorkD23 + 7) * B], Pn[tix(3, 3)]);
+        }
     }
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
@@ -579,45 +646,34 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
             for (int c = r; c < 4; ++c) Pn[tix(r, c)] = fma(m[r] - xp[r], m[c] - xp[c], Pn[tix(r, c)]);
         }
     }
-    int gst = 0;
-    if (kGains && work) {
+    if (kGains && work && full_row) {
         // P_b is centred on the filtered mean x_k, not on the predicted one (unscented.py:324-325): with b = x^- - x_k,
-        // e = (weighted mean) - x^-,  P_b = P^- + e b^T + b e^T + b b^T; then the gain K = D pinv(P_b) (:333)
+        // e = (weighted mean) - x^-,  P_b = P^- + e b^T + b e^T + b b^T
         double* w = work + (nrow * kWorkElems) * B + t;
-        double bv[4], Pb[10], K[4][4];
+        double bv[4];
         STE_UNROLL
         for (int c = 0; c < 4; ++c) bv[c] = xp[c] - x[c];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            double xb = m[c];
+            if (noise_rts) xb += noise_rts[(nrow * 4 + c) * B + t];
+            st_stream(&w[(kWorkXb + c) * B], xb);
+        }
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
             for (int c = r; c < 4; ++c) {
                 double v = fma(bv[r], bv[c], Pn[tix(r, c)]);
                 if (noise) v += fma(m[r] - xp[r], bv[c], bv[r] * (m[c] - xp[c]));
-                Pb[tix(r, c)] = v;
+                st_stream(&w[(kWorkPb + tix(r, c)) * B], v);
             }
-        }
-        gst = smoother_gain(Pb, D, all_eig, K);
-        STE_UNROLL
-        for (int r = 0; r < 4; ++r) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) st_stream(&w[(kWorkK + r * 4 + c) * B], K[r][c]);
-        }
-        if (full_row) {
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) {
-                double xb = m[c];
-                if (noise_rts) xb += noise_rts[(nrow * 4 + c) * B + t];
-                st_stream(&w[(kWorkXb + c) * B], xb);
-            }
-            STE_UNROLL
-            for (int e = 0; e < 10; ++e) st_stream(&w[(kWorkPb + e) * B], Pb[e]);
         }
     }
     STE_UNROLL
     for (int c = 0; c < 4; ++c) x[c] = xp[c];
     STE_UNROLL
     for (int e = 0; e < 10; ++e) P[e] = Pn[e];
-    return st | gst;
+    return st;
 }
 
 // Measurement update on packed (x, P): the closed form for H = diag(1, 1, 0, 0) (kFastUpd, chosen by launch_forward from
@@ -656,11 +712,7 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
                                            const double (&P)[10]) {
     STE_UNROLL
     for (int c = 0; c < 4; ++c) st_stream(&p.fwd_mean[(row * 4 + c) * B + t], x[c]);
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) st_stream(&p.fwd_cov[(row * 16 + r * 4 + c) * B + t], P[tix(r, c)]);
-    }
+    store_cov_p(p.fwd_cov, (p.flags & STE_FLAG_PACKED_COV) != 0, row, B, t, P);
 }
 
 // One wave per SIMD, on purpose: the step loop issues a vector instruction in ~80 % of its cycles, so a second forward
@@ -700,7 +752,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int st = 0;
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
-    const bool all_eig = (p.tuning & 0x100) != 0;
+    bool flagged = false;  // sticky: a square root of this track was clamped or did not converge
+    double* first_bad = (kGains && p.rts_work) ? p.rts_work + ((size_t)p.Nmax * kWorkElems) * B + t : nullptr;
+    if (first_bad) *first_bad = kNeverBad;
     double V[4][4];
     if (kGains && initial_update && ns > 0) {
         // History row 0 is the PRIOR (kalman_filter.py:76-77) while the first predict starts from the state after the
@@ -712,7 +766,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         STE_UNROLL
         for (int e = 0; e < 10; ++e) Pc[e] = P[e];
         st |= lane_predict<true>(p.m, xc, Pc, V, false, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts, 0, B, t,
-                                 p.rts_work, true, all_eig);
+                                 p.rts_work, true, flagged, first_bad);
     }
     if (initial_update) {
         double z0[4];
@@ -754,7 +808,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             const bool warm = (k & (kColdEvery - 1)) != 0;
             st |= lane_predict<kGains>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
-                                       upd || noise_mode, all_eig);
+                                       upd || noise_mode, flagged, first_bad);
             if (upd) st |= lane_update<kFastUpd>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_hist(p, (size_t)k + 1, B, t, x, P);
@@ -783,7 +837,7 @@ __device__ __forceinline__ int tri_index(int r, int c) { return r * 4 - (r * (r 
 __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
                                             QuadBasis& basis, double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, double* work, size_t nrow, size_t B, size_t t,
-                                            bool full_row, bool all_eig) {
+                                            bool full_row, bool& flagged, double* first_bad) {
     double Tn[4], s0[4], sp[4], sm[4], m[4], xp[4];
     int st = quad_sym_sqrt(Px, p.fan_scale, cx, basis, Tn);
     quad_propagate(x, Tn, dt, sr, cr, s0, sp, sm);
@@ -831,43 +885,31 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
             for (int s = 0; s < 4; ++s) Pb[s] += fma(ex[0], bx[s], bx[0] * ex[s]);
         }
         double* w = work + (nrow * kWorkElems) * B + t;
-        // row q of D: columns 0-1 from the +- pair differences above, columns 2-3 = 2 wi (T T)[q][2:4] (speed and heading
-        // pass through the process model with unit slope)
-        double Dq[4];
-        Dq[0] = p.wi * D[0];
-        Dq[1] = p.wi * D[1];
         STE_UNROLL
-        for (int c = 2; c < 4; ++c) {
-            double acc = Tn[0] * bcast<0>(Tn[c]);
-            acc = fma(Tn[1], bcast<1>(Tn[c]), acc);
-            acc = fma(Tn[2], bcast<2>(Tn[c]), acc);
-            acc = fma(Tn[3], bcast<3>(Tn[c]), acc);
-            Dq[c] = (p.wi + p.wi) * acc;
-        }
-        // the whole of P_b in every lane (natural order rows arrive by quad broadcasts), then this lane's row of
-        // K = D pinv(P_b) (unscented.py:333) by the same factorisation / eigenvalue routes as the lane-per-track kernel
-        double Pbn[4];
-        xorperm(Pb, q, Pbn);  // row q of P_b, natural order
-        double Pbp[10];
-        Pbp[tix(0, 0)] = bcast<0>(Pbn[0]);
-        Pbp[tix(0, 1)] = bcast<0>(Pbn[1]);
-        Pbp[tix(0, 2)] = bcast<0>(Pbn[2]);
-        Pbp[tix(0, 3)] = bcast<0>(Pbn[3]);
-        Pbp[tix(1, 1)] = bcast<1>(Pbn[1]);
-        Pbp[tix(1, 2)] = bcast<1>(Pbn[2]);
-        Pbp[tix(1, 3)] = bcast<1>(Pbn[3]);
-        Pbp[tix(2, 2)] = bcast<2>(Pbn[2]);
-        Pbp[tix(2, 3)] = bcast<2>(Pbn[3]);
-        Pbp[tix(3, 3)] = bcast<3>(Pbn[3]);
-        double Kq[4];
-        st |= quad_smoother_gain(Pbp, Dq, all_eig, Kq);
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) w[(kWorkK + q * 4 + c) * B] = Kq[c];
-        if (full_row) {  // elsewhere the smoother rebuilds x_b and P_b from history rows k and k + 1 (see kWorkK)
+        for (int c = 0; c < 2; ++c) w[(kWorkD + q * 2 + c) * B] = p.wi * D[c];  // row q of D, columns 0-1
+        if (full_row) {  // elsewhere the smoother rebuilds x_b and P_b from history rows k and k + 1 (see kWorkD)
             w[(kWorkXb + q) * B] = sel4(xb, q);
             STE_UNROLL
-            for (int c = 0; c < 4; ++c) {
-                if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pbn[c];
+            for (int s = 0; s < 4; ++s) {
+                const int c = q ^ s;
+                if (c >= q) w[(kWorkPb + tri_index(q, c)) * B] = Pb[s];
+            }
+        }
+        int stq = st & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV);  // each lane saw its own eigenvalue: combine over the quad
+        stq |= dpp_move_i<0xB1>(stq);
+        stq |= dpp_move_i<0x4E>(stq);
+        const bool bad_now = stq != 0;
+        if (bad_now && !flagged && q == 0) *first_bad = (double)nrow;
+        flagged = flagged || bad_now;
+        if (flagged) {
+            // columns 2-3 of D (row q): 2 wi (T T)[q][2:4] -- (2 wi scale) P_k[q][2:4] only for an exact square root
+            STE_UNROLL
+            for (int c = 2; c < 4; ++c) {
+                double acc = Tn[0] * bcast<0>(Tn[c]);
+                acc = fma(Tn[1], bcast<1>(Tn[c]), acc);
+                acc = fma(Tn[2], bcast<2>(Tn[c]), acc);
+                acc = fma(Tn[3], bcast<3>(Tn[c]), acc);
+                w[(kWorkD23 + q * 2 + (c - 2)) * B] = (p.wi + p.wi) * acc;
             }
         }
     }
@@ -1021,13 +1063,21 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     auto store_row = [&](size_t row) {
         p.fwd_mean[(row * 4 + q) * B + t] = sel4(x, q);
         STE_UNROLL
-        for (int k = 0; k < 4; ++k) p.fwd_cov[(row * 16 + q * 4 + (q ^ k)) * B + t] = Px[k];
+        for (int k = 0; k < 4; ++k) {
+            const int c = q ^ k;
+            if (!(p.flags & STE_FLAG_PACKED_COV))
+                p.fwd_cov[(row * 16 + q * 4 + c) * B + t] = Px[k];
+            else if (c >= q)
+                p.fwd_cov[(row * 10 + tri_index(q, c)) * B + t] = Px[k];
+        }
     };
     store_row(0);  // slot 0 = prior (kalman_filter.py:76-77)
 
     int st = 0;
+    bool flagged = false;
+    double* first_bad = (kGains && p.rts_work) ? p.rts_work + ((size_t)p.Nmax * kWorkElems) * B + t : nullptr;
+    if (first_bad && q == 0) *first_bad = kNeverBad;
     const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
-    const bool all_eig = (p.tuning & 0x100) != 0;
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     if (kGains && initial_update && ns > 0) {
         // smoother step 0 reads history row 0 = the prior, not the state the first predict starts from
@@ -1040,7 +1090,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
         QuadBasis cold;
         cold.valid = false;
         st |= quad_predict(p.m, cx, xc, Pc, cold, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts,
-                           p.rts_work, 0, B, t, true, all_eig);
+                           p.rts_work, 0, B, t, true, flagged, first_bad);
     }
     if (initial_update) {
         double z0[4];
@@ -1078,7 +1128,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t,
-                               (ui >= 0 && ui_ok) || noise_mode, all_eig);
+                               (ui >= 0 && ui_ok) || noise_mode, flagged, first_bad);
             if (ui >= 0 && ui_ok) st |= quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_row((size_t)k + 1);
@@ -1110,16 +1160,17 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     // row ns: smoothed = filtered
     double xs[4], Ps[4][4];
     load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
-    load_mat(p.fwd_cov, (size_t)ns, B, t, Ps);
+    const bool packed = (p.flags & STE_FLAG_PACKED_COV) != 0;
+    load_cov_m(p.fwd_cov, packed, (size_t)ns, B, t, Ps);
     store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-    store_mat(p.sm_cov, (size_t)ns, B, t, Ps);
+    store_cov_m(p.sm_cov, packed, (size_t)ns, B, t, Ps);
 
     // filtered row of the first step to process, prefetched
     double xn[4] = {0, 0, 0, 0}, Pn[4][4] = {};
     double dt_n = 0.0, sr_n = 0.0, cr_n = 0.0;
     if (ns > 0) {
         load_vec(p.fwd_mean, (size_t)ns - 1, B, t, xn);
-        load_mat(p.fwd_cov, (size_t)ns - 1, B, t, Pn);
+        load_cov_m(p.fwd_cov, packed, (size_t)ns - 1, B, t, Pn);
         const size_t o = (size_t)(ns - 1) * B + t;
         dt_n = p.dt[o];
         sr_n = srp[o];
@@ -1142,7 +1193,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
             const double dt = dt_n, sr = sr_n, cr = cr_n;
             if (k > 0) {
                 load_vec(p.fwd_mean, (size_t)k - 1, B, t, xn);
-                load_mat(p.fwd_cov, (size_t)k - 1, B, t, Pn);
+                load_cov_m(p.fwd_cov, packed, (size_t)k - 1, B, t, Pn);
                 const size_t o = (size_t)(k - 1) * B + t;
                 dt_n = p.dt[o];
                 sr_n = srp[o];
@@ -1214,7 +1265,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
                 for (int c = 0; c < 4; ++c) Ps[r][c] = Pk[r][c] + U[r][c];
             }
             store_vec(p.sm_mean, (size_t)k, B, t, xs);
-            store_mat(p.sm_cov, (size_t)k, B, t, Ps);
+            store_cov_m(p.sm_cov, packed, (size_t)k, B, t, Ps);
         }
     }
     if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
@@ -1222,14 +1273,16 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// URTSS backward pass from the rows the forward pass left in rts_work: the recurrence of unscented.py:337-349,
+// URTSS backward pass from the rows the forward pass left in rts_work: per step the gain K = D pinv(P_b)
+// (unscented.py:333) and the recurrence of :337-349,
 //     y = x^s_{k+1} - x_b (heading wrapped),  x^s_k = x_k + K y,  P^s_k = P_k + K (P^s_{k+1} - P_b) K^T,
-// one lane per track.  The gain K comes from the work row; x_b and P_b from the work row where they were stored (see
-// kWorkK) and otherwise from the filtered rows k and k + 1 the recurrence reads anyway.  Per track-step it reads 16 + 14
-// doubles (K; mean and upper triangle of the filtered covariance), plus 14 on the steps that were followed by an
-// update, and writes the 20 of the smoothed row.  No LDS, no barriers: the kernel is a chain of ~170 fp64 instructions
-// per step whose loads are one row ahead; it is meant to run beside the forward passes of the next batches, whose
-// waves take the issue slots it leaves (batch.SmootherPipeline).  Only reads the work rows: repeatable.
+// one lane per track.  Columns 0-1 of D come from the work row, columns 2-3 from the filtered covariance of row k (or the
+// work row, at and after the track's first bad square root); x_b and P_b from the work row where they were stored (see
+// kWorkD) and otherwise from the filtered rows k and k + 1 the recurrence reads anyway.  Per track-step it reads 8 + 14
+// doubles (D; mean and upper triangle of the filtered covariance), plus 14 on the steps that were followed by an
+// update, and writes the 20 of the smoothed row.  No LDS, no barriers: the kernel is a chain of ~300 fp64 instructions
+// per step whose loads are one row ahead; it is meant to run beside the forward passes of the next batches, whose waves
+// take the issue slots it leaves (batch.SmootherPipeline).  Only reads the work rows: repeatable.
 // ---------------------------------------------------------------------------------------------------------------
 // Is work row k "full" (x_b and P_b stored)?  Mirrors the forward kernels' choice: full when the step was followed by a
 // measurement update (ui = upd_idx[k] names a valid observation), for row 0 of a run that starts with an update, and
@@ -1239,18 +1292,14 @@ __device__ __forceinline__ bool work_row_full(const KParams& p, int k, int ui, b
 }
 
 struct RecurRow {
-    double K[16], xk[4], Pk[10];  // gain of step k; filtered mean and covariance (packed) of row k
+    double D2[8], xk[4], Pk[10];  // columns 0-1 of D of step k; filtered mean and covariance (packed) of row k
 };
 __device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_t B, size_t t, RecurRow& g) {
     const double* w = p.rts_work + (k * kWorkElems) * B + t;
     STE_UNROLL
-    for (int e = 0; e < 16; ++e) g.K[e] = w[(kWorkK + e) * B];
+    for (int e = 0; e < 8; ++e) g.D2[e] = w[(kWorkD + e) * B];
     load_vec(p.fwd_mean, k, B, t, g.xk);
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = r; c < 4; ++c) g.Pk[tix(r, c)] = p.fwd_cov[(k * 16 + r * 4 + c) * B + t];
-    }
+    load_cov_p(p.fwd_cov, (p.flags & STE_FLAG_PACKED_COV) != 0, k, B, t, g.Pk);
 }
 
 __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
@@ -1259,23 +1308,20 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     if (t >= B) return;
     const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
     const bool always_full = p.noise_pred || p.noise_upd || p.noise_rts;
+    const bool all_eig = (p.tuning & 0x100) != 0;
+    const double kappa = (p.m.wi + p.m.wi) * p.m.fan_scale;  // D[:, 2:4] = kappa P_k[:, 2:4] for an exact square root
+    // first step at and after which this track's columns 2-3 of D are stored (kNeverBad: never)
+    const double first_bad = p.rts_work[((size_t)p.Nmax * kWorkElems) * B + t];
     const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
     auto clampk = [&](int k) -> int { return min(max(k, 0), last_row); };
 
     // row ns: smoothed = filtered; it is also "filtered row k + 1" of the first step
     double xs[4], Ps[10], xn[4], Pn[10];
+    const bool packed = (p.flags & STE_FLAG_PACKED_COV) != 0;
     load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = r; c < 4; ++c) Ps[tix(r, c)] = p.fwd_cov[((size_t)ns * 16 + r * 4 + c) * B + t];
-    }
+    load_cov_p(p.fwd_cov, packed, (size_t)ns, B, t, Ps);
     store_vec(p.sm_mean, (size_t)ns, B, t, xs);
-    STE_UNROLL
-    for (int r = 0; r < 4; ++r) {
-        STE_UNROLL
-        for (int c = 0; c < 4; ++c) st_stream(&p.sm_cov[((size_t)ns * 16 + r * 4 + c) * B + t], Ps[tix(r, c)]);
-    }
+    store_cov_p(p.sm_cov, packed, (size_t)ns, B, t, Ps);
     STE_UNROLL
     for (int c = 0; c < 4; ++c) xn[c] = xs[c];
     STE_UNROLL
@@ -1317,6 +1363,27 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
                 STE_UNROLL
                 for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
             }
+            // the gain K = D pinv(P_b) (unscented.py:333)
+            double D[4][4], K[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                D[r][0] = cur.D2[r * 2 + 0];
+                D[r][1] = cur.D2[r * 2 + 1];
+                D[r][2] = kappa * cur.Pk[tix(r, 2)];
+                D[r][3] = kappa * cur.Pk[tix(r, 3)];
+            }
+            if (__builtin_expect(__any((double)k >= first_bad), 0)) {
+                if ((double)k >= first_bad) {
+                    const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
+                    STE_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        D[r][2] = w[(kWorkD23 + r * 2 + 0) * B];
+                        D[r][3] = w[(kWorkD23 + r * 2 + 1) * B];
+                    }
+                }
+            }
+            st |= smoother_gain(Pb, D, all_eig, K);
+            // the row of the next step: in flight during the recurrence arithmetic below (and across the loop edge)
             {
                 const int kn = clampk(k - 1);
                 load_recur_row(p, (size_t)kn, B, t, nxt);
@@ -1330,7 +1397,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             for (int r = 0; r < 4; ++r) {
                 double acc = cur.xk[r];
                 STE_UNROLL
-                for (int c = 0; c < 4; ++c) acc = fma(cur.K[r * 4 + c], y[c], acc);
+                for (int c = 0; c < 4; ++c) acc = fma(K[r][c], y[c], acc);
                 xs[r] = acc;
             }
             xs[3] = floored_mod(xs[3], 360.0);
@@ -1343,9 +1410,9 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             for (int r = 0; r < 4; ++r) {
                 STE_UNROLL
                 for (int c = 0; c < 4; ++c) {
-                    double acc = cur.K[r * 4 + 0] * dP[tix(0, c)];
+                    double acc = K[r][0] * dP[tix(0, c)];
                     STE_UNROLL
-                    for (int i = 1; i < 4; ++i) acc = fma(cur.K[r * 4 + i], dP[tix(i, c)], acc);
+                    for (int i = 1; i < 4; ++i) acc = fma(K[r][i], dP[tix(i, c)], acc);
                     KdP[r][c] = acc;
                 }
             }
@@ -1353,18 +1420,14 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             for (int r = 0; r < 4; ++r) {
                 STE_UNROLL
                 for (int c = r; c < 4; ++c) {
-                    double acc = KdP[r][0] * cur.K[c * 4 + 0];
+                    double acc = KdP[r][0] * K[c][0];
                     STE_UNROLL
-                    for (int i = 1; i < 4; ++i) acc = fma(KdP[r][i], cur.K[c * 4 + i], acc);
+                    for (int i = 1; i < 4; ++i) acc = fma(KdP[r][i], K[c][i], acc);
                     Ps[tix(r, c)] = cur.Pk[tix(r, c)] + acc;
                 }
             }
             store_vec(p.sm_mean, (size_t)k, B, t, xs);
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) st_stream(&p.sm_cov[((size_t)k * 16 + r * 4 + c) * B + t], Ps[tix(r, c)]);
-            }
+            store_cov_p(p.sm_cov, packed, (size_t)k, B, t, Ps);
             // row k becomes "row k + 1" of the next step
             STE_UNROLL
             for (int c = 0; c < 4; ++c) xn[c] = cur.xk[c];
@@ -1622,7 +1685,7 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_mean = b->sm_mean;
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
-    // the forward pass can form the smoother's gains only when both passes use the same rates (see kWorkK)
+    // the forward pass can leave the smoother's rows only when both passes use the same rates (see kWorkD)
     kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts) ? nullptr : b->rts_work;
     return STE_OK;
 }

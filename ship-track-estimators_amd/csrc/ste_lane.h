@@ -344,6 +344,28 @@ __device__ __forceinline__ int sym_pinv_p(const double (&A)[10], double (&Ai)[10
     return st;
 }
 
+// K = D pinv(P_b) by the eigenvalue route, out of line: it is the rare path of smoother_gain (P_b close to singular, or a
+// test asking for it), and inlined its Jacobi working set would set the register allocation of the whole smoother
+// kernel.  Arguments live in memory (the caller's stack), which is what keeps the hot path's arrays in registers.
+__device__ __noinline__ int smoother_gain_eig(const double* pb, const double* d, double* k) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    double Pb[10], Pbi[10];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) Pb[e] = pb[e];
+    const int st = sym_pinv_p(Pb, Pbi);
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) {
+            double acc = d[r * 4 + 0] * Pbi[tix(0, c)];
+            STE_UNROLL
+            for (int i = 1; i < 4; ++i) acc = fma(d[r * 4 + i], Pbi[tix(i, c)], acc);
+            k[r * 4 + c] = acc;
+        }
+    }
+    return st;
+}
+
 // The smoother's gain K = D pinv(P_b) (unscented.py:333) for one step: by an unpivoted L D L^T solve where P_b is safely
 // invertible (pinv is then the inverse; agreement ~ cond(P_b) 2^-52), by the eigenvalue route -- with NumPy's rank
 // cutoff -- for the lanes where a pivot falls under kLdlPivotTol of the largest diagonal entry, and for every lane when
@@ -354,19 +376,21 @@ __device__ __forceinline__ int smoother_gain(const double (&Pb)[10], const doubl
     const bool bad = ldl_right_solve4(Pb, D, K) || all_eig;
     int st = 0;
     if (__builtin_expect(__any(bad), 0)) {
-        double Pbi[10];
-        const int pst = sym_pinv_p(Pb, Pbi);
+        double pbm[10], dm[16], km[16];
+        STE_UNROLL
+        for (int e = 0; e < 10; ++e) pbm[e] = Pb[e];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) dm[r * 4 + c] = D[r][c];
+        }
+        const int pst = smoother_gain_eig(pbm, dm, km);
         if (bad) {
             st = pst;
             STE_UNROLL
             for (int r = 0; r < 4; ++r) {
                 STE_UNROLL
-                for (int c = 0; c < 4; ++c) {
-                    double acc = D[r][0] * Pbi[tix(0, c)];
-                    STE_UNROLL
-                    for (int i = 1; i < 4; ++i) acc = fma(D[r][i], Pbi[tix(i, c)], acc);
-                    K[r][c] = acc;
-                }
+                for (int c = 0; c < 4; ++c) K[r][c] = km[r * 4 + c];
             }
         }
     }

@@ -19,6 +19,7 @@ STE_FLAG_NO_INITIAL_UPDATE = 0x2
 STE_FLAG_ROBUST = 0x4
 STE_FLAG_LANES_1 = 0x10
 STE_FLAG_LANES_4 = 0x20
+STE_FLAG_PACKED_COV = 0x40
 
 STE_RTS_WORK_ROWS = 30  # doubles per (step, track) of ste_ukf_batch_f64.rts_work
 

@@ -305,8 +305,11 @@ class DeviceBatch:
     _IN = ("nsteps", "x0", "P0", "dt", "sog_rate", "cog_rate", "sog_rate_rts", "cog_rate_rts", "upd_idx", "z",
            "noise_pred", "noise_upd", "noise_rts")
 
+    # position of (r, c) in a packed upper triangle, for all 16 entries of the full matrix (include/ste.h: STE_FLAG_PACKED_COV)
+    _PACKED_INDEX = [min(r, c) * 4 - (min(r, c) * (min(r, c) - 1)) // 2 + abs(r - c) for r in range(4) for c in range(4)]
+
     def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True, fuse_gains: bool = True,
-                 tuning: int = 0):
+                 tuning: int = 0, packed_cov: bool = True):
         import torch
 
         self.lib = binding.require_gpu()
@@ -320,14 +323,18 @@ class DeviceBatch:
         B, N = hb.B, hb.Nmax
         f64 = dict(dtype=torch.float64, device=self.device)
         self.fwd_mean = torch.empty((N + 1, 4, B), **f64)
-        self.fwd_cov = torch.empty((N + 1, 16, B), **f64)
+        # covariance histories as upper triangles on the device (they are symmetric by construction); download()
+        # expands them to the reference's (.., 4, 4).  packed_cov=False keeps full matrices in HBM.
+        self.packed_cov = bool(packed_cov)
+        cov_rows = 10 if self.packed_cov else 16
+        self.fwd_cov = torch.empty((N + 1, cov_rows, B), **f64)
         self.sm_mean = torch.empty((N + 1, 4, B), **f64) if alloc_smoothed else None
-        self.sm_cov = torch.empty((N + 1, 16, B), **f64) if alloc_smoothed else None
+        self.sm_cov = torch.empty((N + 1, cov_rows, B), **f64) if alloc_smoothed else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         # workspace for the smoother gains the forward pass can produce on the way (include/ste.h: rts_work)
         self.rts_work = None
         if alloc_smoothed and fuse_gains and hb.sog_rate_rts is None and hb.cog_rate_rts is None and N > 0:
-            self.rts_work = torch.empty((N, binding.STE_RTS_WORK_ROWS, B), **f64)
+            self.rts_work = torch.empty((N * binding.STE_RTS_WORK_ROWS + 1, B), **f64)  # include/ste.h: rts_work
         fan_scale, w0, wi = sigma_constants(4, hb.weights_computed)
         self._keep = (hb.H, hb.Q, hb.R)
         s = binding.SteUkfBatchF64()
@@ -337,7 +344,8 @@ class DeviceBatch:
             raise ValueError(f"lanes must be 0 (automatic), 1 or 4, got {lanes!r}")
         s.flags = (binding.STE_FLAG_SHARED_P0 if hb.shared_p0 else 0) | (
             0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE) | (
-            binding.STE_FLAG_ROBUST if hb.robust else 0) | {0: 0, 1: binding.STE_FLAG_LANES_1, 4: binding.STE_FLAG_LANES_4}[lanes]
+            binding.STE_FLAG_ROBUST if hb.robust else 0) | {0: 0, 1: binding.STE_FLAG_LANES_1, 4: binding.STE_FLAG_LANES_4}[lanes] | (
+            binding.STE_FLAG_PACKED_COV if self.packed_cov else 0)
         s.tuning = int(tuning)
         s.chi_alpha, s.robust_max_iter = float(hb.chi_alpha), 50
         s.fan_scale, s.w0, s.wi = fan_scale, w0, wi
@@ -396,6 +404,10 @@ class DeviceBatch:
                 raise ValueError(f"{name} was not computed for this batch (alloc_smoothed=False)")
             if track_index is not None:
                 t = t.index_select(2, track_index)
+            if width == 16 and self.packed_cov:  # upper triangles -> full symmetric matrices, still on the device
+                if getattr(self, "_packed_index_t", None) is None:
+                    self._packed_index_t = torch.tensor(self._PACKED_INDEX, dtype=torch.int64, device=self.device)
+                t = t.index_select(1, self._packed_index_t)
             dev_t = t.permute(2, 0, 1).contiguous()  # (B, N+1, width) on the device
             host = torch.empty(dev_t.shape, dtype=dev_t.dtype, pin_memory=True)
             host.copy_(dev_t, non_blocking=True)
@@ -422,18 +434,22 @@ class DeviceBatch:
 
 class SmootherPipeline:
     """
-    Forward passes and smoothers of consecutive batches on disjoint parts of the GPU, several in flight.
+    Forward passes and smoothers of consecutive batches side by side on the GPU, several of each in flight.
 
-    A batch of BASELINE size (10 000 tracks) is a few hundred long-running forward waves on 1 024 SIMDs followed by a
-    memory-bound smoother.  Run back to back they leave most of the chip idle; run side by side on ordinary streams
-    they land on the same SIMDs and take each other's issue slots.  Here forward passes run on streams restricted to
-    the first ``forward_cus`` compute units and smoothers on streams restricted to the rest
-    (``ste_stream_create_cu_range``).  By default the forward passes run with one lane per track (``forward_lanes``):
-    157 waves per 10 000-track batch, half the instructions per track of the quad mapping that is best for a batch on
-    its own, and as many of them in flight as fill the partition's SIMDs (``forward_streams``: four at 10 000 tracks on
-    160 CUs); the smoothers of two batches share the other CUs, whose waves mostly wait for memory.  Each ``DeviceBatch`` owns
-    its histories and work rows; a batch is not resubmitted before its previous smoother has finished (events), so the
-    caller rotates through ``buffers_needed`` or more of them.
+    A batch of BASELINE size (10 000 tracks) is 157 long-running forward waves on 1 024 SIMDs followed by a smoother that
+    is a latency chain (one wave per 64 tracks, ~1.5 us per step); run back to back they leave most of the chip idle.
+    Two ways to overlap consecutive batches, both on streams that own a hardware queue each
+    (``ste_stream_create_cu_range``; ordinary HIP streams share a handful of queues and their launches serialise):
+
+    ``shared=True`` (default)  every stream may use every compute unit.  A lane-per-track forward wave is built to hold
+        264 registers -- one per SIMD, never two -- and a smoother wave 232, so the smoothers of earlier batches slot in
+        beside the forward waves of later ones and take the issue slots those leave (a forward wave issues ~80 % of its
+        cycles; a smoother wave mostly waits for memory).  ``forward_streams`` forward passes fill the chip's SIMDs
+        (seven at 10 000 tracks), ``smoother_streams`` smoothers hide each other's latency (five).
+    ``shared=False``  round 1-2's split: forward passes on the first ``forward_cus`` compute units, smoothers on the rest.
+
+    Each ``DeviceBatch`` owns its histories and work rows; a batch is not resubmitted before its previous smoother has
+    finished (events), so the caller rotates through ``buffers_needed`` or more of them.
 
         with SmootherPipeline(device, ntracks=hb.B) as pipe:
             dbs = [DeviceBatch(hb, device) for _ in range(pipe.buffers_needed)]
@@ -446,8 +462,8 @@ class SmootherPipeline:
     """
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
-                 forward_streams: Optional[int] = None, smoother_streams: int = 2, forward_lanes: int = 1,
-                 shared: bool = False):
+                 forward_streams: Optional[int] = None, smoother_streams: Optional[int] = None, forward_lanes: int = 1,
+                 shared: Optional[bool] = None):
         import torch
 
         self.torch = torch
@@ -458,6 +474,8 @@ class SmootherPipeline:
         self.forward_lanes = int(forward_lanes)
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
         quad = forward_lanes == 4 or (forward_lanes == 0 and (ntracks or 10_000) <= 32_768)
+        if shared is None:  # naming a forward partition asks for the split; otherwise everything shares the chip
+            shared = forward_cus is None
         self.shared = bool(shared)
         if shared:
             # no partition: forward passes and smoothers on streams that each own a hardware queue but may use every CU.
@@ -482,7 +500,14 @@ class SmootherPipeline:
             nt = ntracks or 10_000
             waves = -(-nt * 4 // 64) if quad else -(-nt // 64)
             slots = forward_cus * (8 if quad else 4)
-            forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(8, (2 * slots + waves) // (2 * waves)))
+            if shared:  # fill the SIMDs (rounded up: the waves of the last pass start as slots come free), at most eight
+                forward_streams = max(1, min(8, -(-slots // waves)))
+            else:
+                forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(8, (2 * slots + waves) // (2 * waves)))
+        if smoother_streams is None:
+            # shared: measured at 10 000 and 12 500 tracks (profiles/r03_pipeline_sweeps.txt): throughput is flat from five
+            # smoothers in flight on; fewer leave their latency exposed
+            smoother_streams = 5 if shared else 2
         if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:

@@ -254,7 +254,7 @@ class UnscentedKalmanFilter(KalmanFilterBase):
             sog_rate_rts=None, cog_rate_rts=None, upd_idx=np.full((N, 1), -1, dtype=np.int32), z=np.zeros((1, 4, 1)),
             noise_pred=None, noise_upd=None, noise_rts=nrts.reshape(N, 4, 1))
         # the history comes from the caller, not from a forward launch on this batch: no precomputed gains
-        db = _batch.DeviceBatch(hb, fuse_gains=False)
+        db = _batch.DeviceBatch(hb, fuse_gains=False, packed_cov=False)  # the caller's full matrices go in as they are
         db.fwd_mean.copy_(_up(torch, dev, m, (nrows, 4, 1)))
         db.fwd_cov.copy_(_up(torch, dev, fwd_vars, (nrows, 16, 1)))
         db.backward()

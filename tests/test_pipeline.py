@@ -1,5 +1,6 @@
-"""batch.SmootherPipeline: forward passes and smoothers of consecutive batches on disjoint CU partitions give the same
-bits as running each batch alone, in any interleaving, and a batch is not resubmitted before its smoother has drained."""
+"""batch.SmootherPipeline: forward passes and smoothers of consecutive batches side by side (sharing every CU, or on
+disjoint CU partitions) give the same bits as running each batch alone, in any interleaving, and a batch is not
+resubmitted before its smoother has drained."""
 import numpy as np
 import pytest
 
@@ -27,7 +28,7 @@ def test_pipeline_matches_serial_runs():
         want.append((db.sm_mean.clone(), db.sm_cov.clone(), db.fwd_mean.clone()))
     dbs = [batch.DeviceBatch(hb) for hb in hbs]
     pipe = batch.SmootherPipeline("cuda:0", ntracks=300)
-    assert pipe.forward_cus % 8 == 0 and pipe.smoother_cus > 0
+    assert pipe.shared and pipe.forward_cus == pipe.smoother_cus  # default: every stream may use every CU
     order = [0, 1, 2, 1, 0, 2, 2, 0, 1]
     for i, k in enumerate(order):
         pipe.submit(dbs[k], final=(i == len(order) - 1))
@@ -86,8 +87,8 @@ def test_pipeline_full_size_matches_serial():
     err = (quad.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
     assert float(err.max()) < 1e-7  # the two lane mappings round differently, nothing more (tolerance: 1e-6)
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 4, 2)
-    assert pipe.buffers_needed == 7
+    assert (pipe.shared, pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 256, 256, 7, 5)
+    assert pipe.buffers_needed == 13
     dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
     for k in range(8):
         pipe.submit(dbs[k % 3], final=(k == 7))
@@ -97,11 +98,35 @@ def test_pipeline_full_size_matches_serial():
         assert torch.equal(db.sm_mean, ref.sm_mean) and torch.equal(db.sm_cov, ref.sm_cov)
         assert not db.status_host().any()
     pipe.close()
+    # the round-2 split (forward passes and smoothers on disjoint CU partitions) is still there, and gives the same bits
+    with batch.SmootherPipeline("cuda:0", ntracks=hb.B, shared=False) as part:
+        assert (part.shared, part.forward_cus, part.smoother_cus, len(part.bwd_streams)) == (False, 160, 96, 2)
+        for k in range(5):
+            part.submit(dbs[k % 3], final=(k == 4))
+        part.synchronize()
+    for db in dbs:
+        assert torch.equal(db.sm_mean, ref.sm_mean) and torch.equal(db.sm_cov, ref.sm_cov)
+    # full size against the oracle: filtered AND smoothed, means AND covariances, on 256 of the 10 000 tracks
+    from oracle import ukf_oracle as orc
+
+    n = 256
+    fires = hb.upd_idx.T[:n] >= 0
+    zidx = np.where(fires, hb.upd_idx.T[:n], 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
+    rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (n, 500))
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
+    for db in (ref, quad):
+        res = db.download(track_index=torch.arange(n, device=db.device))
+        for name, want, tol in (("means", m, 1e-6), ("means_smoothed", sm, 1e-6)):
+            assert float(np.max(np.abs(res[name] - want) / np.maximum(np.abs(want), 1e-12))) < tol, name
+        for name, want, tol in (("covs", P, 1e-5), ("covs_smoothed", sP, 1e-5)):
+            assert float(np.max(np.abs(res[name] - want) / np.max(np.abs(want), axis=(-1, -2), keepdims=True))) < tol, name
 
 
 def test_pipeline_config2_shard_size():
     """BASELINE.json configs[2]'s shard (100 000 tracks / 8 GPUs = 12 500 tracks x 500 steps) through the default
-    pipeline for that size: the partition is the measured one (160 + 96 CUs, three lane-per-track forward passes in flight), seven
+    pipeline for that size (six lane-per-track forward passes and five smoothers in flight, sharing the chip): seven
     pipelined steps leave exactly the bits of a batch run on its own, and a sample of tracks matches the oracle."""
     import torch
     from oracle import ukf_oracle as orc
@@ -115,8 +140,8 @@ def test_pipeline_config2_shard_size():
     torch.cuda.synchronize()
     hb.lanes = None
     with batch.SmootherPipeline("cuda:0", ntracks=hb.B) as pipe:
-        assert (pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (160, 96, 3, 2)
-        dbs = [batch.DeviceBatch(hb) for _ in range(pipe.buffers_needed)]
+        assert (pipe.shared, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 6, 5)
+        dbs = [batch.DeviceBatch(hb) for _ in range(4)]
         for k in range(7):
             pipe.submit(dbs[k % len(dbs)], final=(k == 6))
         pipe.synchronize()
@@ -130,7 +155,7 @@ def test_pipeline_config2_shard_size():
     m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
     rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (n, 500))
     sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
-    got = ref.sm_mean[:, :, :n].permute(2, 0, 1).cpu().numpy()
+    res = ref.download(("means_smoothed", "covs_smoothed"), torch.arange(n, device=ref.device))
+    got, gotP = res["means_smoothed"], res["covs_smoothed"]
     assert float(np.max(np.abs(got - sm) / np.maximum(np.abs(sm), 1e-12))) < 1e-6
-    gotP = ref.sm_cov[:, :, :n].permute(2, 0, 1).cpu().numpy().reshape(n, 501, 4, 4)
     assert float(np.max(np.abs(gotP - sP) / np.max(np.abs(sP), axis=(-1, -2), keepdims=True))) < 1e-5
