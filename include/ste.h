@@ -279,6 +279,8 @@ int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m
  * A track with fewer than 2 observations has no leg: all outputs 0 (the reference raises IndexError there).
  * ------------------------------------------------------------------------------------------------------------- */
 #define STE_PREP_SPHERE 0 /* haversine_formula + heading on the 6378.137 km sphere (utils.py:75-147) */
+#define STE_PREP_STATUS_NOCONV 0x1 /* WGS84 model: Vincenty's iteration did not converge on some leg of the track (nearly
+                                      antipodal points); the reference's geographiclib would still solve such a leg */
 #define STE_PREP_WGS84 1  /* geographiclib_distance + geographiclib_heading semantics (utils.py:9-72), WGS84 inverse
                              geodesic by Vincenty's iteration */
 
@@ -296,6 +298,7 @@ typedef struct ste_prep_batch_f64 {
     double* sog_rate;     /* [Tmax][B] out */
     double* cog_rate;     /* [Tmax][B] out */
     double* z;            /* [Tmax][4][B] out, may be NULL */
+    int32_t* status;      /* [B] out, may be NULL: STE_PREP_STATUS_* bits per track (reset by the call) */
 } ste_prep_batch_f64;
 
 int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream);

@@ -38,6 +38,7 @@ constexpr double kWgsF = 1.0 / 298.257223563;
 struct Leg {
     double dist_km;
     double head_deg;
+    bool converged;  // false: Vincenty's iteration hit its cap (nearly antipodal points); the sphere model always converges
 };
 
 // utils.py:75-147 — haversine (atan2 form) and the initial great-circle bearing in [0, 360)
@@ -51,6 +52,7 @@ __device__ Leg sphere_leg(double lon1, double lat1, double lon2, double lat2) {
     const double c1 = cos(lat1), c2 = cos(lat2);
     const double a = sh * sh + c1 * c2 * sl * sl;
     Leg r;
+    r.converged = true;
     r.dist_km = 2.0 * atan2(sqrt(a), sqrt(1.0 - a)) * kEarthKm;
     const double east = sin(dlon) * c2;
     const double north = c1 * sin(lat2) - sin(lat1) * c2 * cos(dlon);
@@ -60,7 +62,7 @@ __device__ Leg sphere_leg(double lon1, double lat1, double lon2, double lat2) {
 
 // utils.py:9-72 with Geodesic.WGS84.Inverse replaced by Vincenty's inverse iteration (see the header of this file)
 __device__ Leg wgs84_leg(double lon1, double lat1, double lon2, double lat2) {
-    Leg r{0.0, 0.0};
+    Leg r{0.0, 0.0, true};
     if (fabs(lat1 - lat2) < 1e-8 && fabs(lon1 - lon2) < 1e-8) return r;  // utils.py:32-33, :64-65
     const double b = kWgsA * (1.0 - kWgsF);
     const double phi1 = lat1 * kDeg2Rad, phi2 = lat2 * kDeg2Rad;
@@ -89,8 +91,11 @@ __device__ Leg wgs84_leg(double lon1, double lat1, double lon2, double lat2) {
                     (sigma + Cc * sin_sigma * (cos_2sm + Cc * cos_sigma * (-1.0 + 2.0 * cos_2sm * cos_2sm)));
         const bool done = fabs(lam_new - lam) < 1e-15;
         lam = lam_new;
+        r.converged = done;
         if (done) break;
     }
+    // Vincenty's fixed point does not contract for nearly antipodal points (geographiclib's Karney solver, which the
+    // reference calls, handles them); the values below are then the last iterate's, and the track is flagged.
     sl = sin(lam);
     cl = cos(lam);
     const double u2 = cos2_alpha * (kWgsA * kWgsA - b * b) / (b * b);
@@ -111,6 +116,7 @@ struct PrepParams {
     const int32_t* nobs;
     const double *lon, *lat, *gap;
     double *sog, *cog, *sog_rate, *cog_rate, *z;
+    int32_t* status;
 };
 
 template <int kModel>
@@ -134,6 +140,7 @@ __global__ void __launch_bounds__(256) track_prep(PrepParams p) {
     if (i < n && n >= 2) {
         const int j = min(i, n - 2);
         const Leg cur = leg_of<kModel>(p, j, t);
+        if (kModel == 1 && !cur.converged && p.status) atomicOr(&p.status[t], STE_PREP_STATUS_NOCONV);
         sog = cur.dist_km / p.gap[(size_t)j * p.B + t];
         cog = cur.head_deg;
         if (i >= 1) {
@@ -175,10 +182,15 @@ extern "C" int ste_track_prep_f64(const ste_prep_batch_f64* b, void* stream) {
     if (!b->lon || !b->lat || !b->sog || !b->cog || !b->sog_rate || !b->cog_rate)
         return abi_fail(STE_EINVAL, "lon, lat, sog, cog, sog_rate and cog_rate are required");
     if (b->Tmax > 1 && !b->gap) return abi_fail(STE_EINVAL, "gap is required when Tmax > 1");
-    PrepParams p{b->B, b->Tmax, b->model, b->nobs, b->lon, b->lat, b->gap, b->sog, b->cog, b->sog_rate, b->cog_rate, b->z};
+    PrepParams p{b->B, b->Tmax, b->model, b->nobs, b->lon, b->lat, b->gap, b->sog, b->cog, b->sog_rate, b->cog_rate, b->z,
+                 b->status};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (b->status) {
+        int rc = abi_check_hip(hipMemsetAsync(b->status, 0, sizeof(int32_t) * (size_t)b->B, s), "track_prep status reset");
+        if (rc) return rc;
+    }
     const size_t total = (size_t)b->B * b->Tmax;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (b->model == STE_PREP_SPHERE)
         hipLaunchKernelGGL(track_prep<0>, dim3(grid), dim3(256), 0, s, p);
     else

@@ -116,11 +116,13 @@ class StePrepBatchF64(C.Structure):
         ("sog_rate", _dp),
         ("cog_rate", _dp),
         ("z", _dp),
+        ("status", _dp),
     ]
 
 
 STE_PREP_SPHERE = 0
 STE_PREP_WGS84 = 1
+STE_PREP_STATUS_NOCONV = 0x1
 
 # every symbol include/ste.h declares: (restype, argtypes)
 SYMBOLS = {

@@ -136,11 +136,34 @@ class HostBatch:
         return int(self.nsteps.sum())
 
 
-def _as44(M, name):
+SYMMETRY_RTOL = 1e-12  # |M - M^T| above this fraction of max|M| is "not symmetric" (rounding leaves ~1e-16)
+
+
+def require_symmetric(M, name):
+    """Raise ValueError unless every (.., 4, 4) matrix in ``M`` is symmetric to rounding.
+
+    The kernels treat Q, R and every covariance as symmetric matrices (symmetric square root, eigenvalue pseudo-inverse,
+    packed triangles); the reference calls scipy.linalg.sqrtm / np.linalg.pinv on whatever it is given, and for a
+    non-symmetric argument those are a different computation (Schur form, SVD).  Such input is not a covariance, so it
+    is refused rather than silently symmetrised (hard part 1)."""
+    M = np.asarray(M, dtype=np.float64)
+    asym = np.abs(M - np.swapaxes(M, -1, -2))
+    scale = np.max(np.abs(M), axis=(-1, -2), keepdims=True)
+    bad = ~(asym <= SYMMETRY_RTOL * scale) & np.isfinite(M) & np.isfinite(np.swapaxes(M, -1, -2))
+    if np.any(bad):
+        raise ValueError(f"{name} must be symmetric: max |{name} - {name}^T| = {float(np.max(np.where(bad, asym, 0.0))):.3e}; "
+                         "the HIP path works on symmetric covariances (scipy.linalg.sqrtm / np.linalg.pinv of a "
+                         "non-symmetric matrix, unscented.py:97,243, is a different computation)")
+    return M
+
+
+def _as44(M, name, symmetric: bool = False):
     M = np.ascontiguousarray(np.asarray(M, dtype=np.float64))
     if M.shape != (4, 4):
         raise ValueError(f"{name} must be 4x4 for the HIP path (got {M.shape}); the reference hard-codes the heading at "
                          "index 3 (unscented.py:250)")
+    if symmetric:
+        require_symmetric(M, name)
     return M
 
 
@@ -183,7 +206,7 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
             P0a = np.asarray(P0, dtype=np.float64)
             if P0a.ndim == 3:
                 P0 = P0a[order]
-    H, Q, R = _as44(H, "H"), _as44(Q, "Q"), _as44(R, "R")
+    H, Q, R = _as44(H, "H"), _as44(Q, "Q", True), _as44(R, "R", True)
     Ns = [len(d) for d in dts_per_track]
     Ts = [np.asarray(tr.z).shape[1] for tr in tracks]
     Nmax, Tmax = max(Ns), max(Ts)
@@ -197,7 +220,7 @@ def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, 
     crr = np.zeros((Nmax, B))
     ui = np.full((Nmax, B), -1, dtype=np.int32)
     z = np.zeros((Tmax, 4, B))
-    P0 = np.asarray(P0, dtype=np.float64)
+    P0 = require_symmetric(P0, "P0")
     if P0.shape == (4, 4):
         P0p = np.ascontiguousarray(P0.reshape(16))
     elif P0.shape == (B, 4, 4):
@@ -260,7 +283,7 @@ def pack_uniform(sb, substeps: int, H, Q, R, P0) -> HostBatch:
     Fast path for a batch where every track has the same number of observations (``synthetic.SyntheticBatch``):
     vectorised over tracks.  x0 = z[:, 0] (example_ukf_rts_smoother_batch.py:60); dt = generate_dts(dts, substeps).
     """
-    H, Q, R = _as44(H, "H"), _as44(Q, "Q"), _as44(R, "R")
+    H, Q, R = _as44(H, "H"), _as44(Q, "Q", True), _as44(R, "R", True)
     B, T = sb.lon.shape
     s = int(substeps)
     N = s * (T - 1)
@@ -287,7 +310,7 @@ def pack_uniform(sb, substeps: int, H, Q, R, P0) -> HostBatch:
     if not same_rts:
         srr, crr = sog_t[rr], cog_t[rr]
         same_rts = np.array_equal(sr, srr) and np.array_equal(cr, crr)
-    P0 = np.asarray(P0, dtype=np.float64)
+    P0 = require_symmetric(_as44(P0, "P0"), "P0")
     return HostBatch(
         B=B, Nmax=N, Tmax=T, H=H, Q=Q, R=R, nsteps=np.full(B, N, dtype=np.int32), x0=c(sb.z[:, :, 0].T),
         P0=c(P0.reshape(16)), dt=np.repeat(c(sb.dts.T) / s, s, axis=0), sog_rate=sr, cog_rate=cr,
@@ -676,8 +699,9 @@ def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: 
 
     ``lons[b]``, ``lats[b]`` (length T_b, degrees) and ``gaps[b]`` (length T_b - 1, hours) are what ``ShipTrack.read_csv``
     returns.  ``model`` is ``"wgs84"`` (the ShipTrack defaults, geographiclib_distance / _heading) or ``"sphere"``
-    (haversine_formula / heading).  Returns one dict per track with ``sog, cog, sog_rate, cog_rate`` (length T_b) and
-    ``z`` (4, T_b) = the result of ``get_measurements(include_sog=True, include_cog=True)`` (ship_track.py:197-338).
+    (haversine_formula / heading).  Returns one dict per track with ``sog, cog, sog_rate, cog_rate`` (length T_b),
+    ``z`` (4, T_b) = the result of ``get_measurements(include_sog=True, include_cog=True)`` (ship_track.py:197-338) and
+    ``status`` (STE_PREP_STATUS_NOCONV = 1: Vincenty's iteration hit its cap on some leg; a RuntimeWarning names the tracks).
     """
     import torch
 
@@ -712,15 +736,24 @@ def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: 
     s.nobs, s.lon, s.lat, s.gap = t_n.data_ptr(), t_lon.data_ptr(), t_lat.data_ptr(), t_gap.data_ptr()
     s.sog, s.cog, s.sog_rate, s.cog_rate = (outs[i].data_ptr() for i in range(4))
     s.z = z.data_ptr()
+    st = torch.zeros((B,), dtype=torch.int32, device=dev)
+    s.status = st.data_ptr()
     stream = torch.cuda.current_stream(dev)
     binding.check(lib.ste_track_prep_f64(C.byref(s), C.c_void_p(stream.cuda_stream)), "ste_track_prep_f64")
     h = outs.cpu().numpy()
     zh = z.cpu().numpy()
+    sth = st.cpu().numpy()
+    if sth.any():
+        import warnings
+
+        warnings.warn(f"WGS84 inverse (Vincenty) did not converge on some leg of track(s) {np.flatnonzero(sth).tolist()} "
+                      "(nearly antipodal observations); their speed / course over ground are approximate", RuntimeWarning,
+                      stacklevel=2)
     res = []
     for b in range(B):
         n = nobs[b]
         res.append({"sog": h[0, :n, b].copy(), "cog": h[1, :n, b].copy(), "sog_rate": h[2, :n, b].copy(),
-                    "cog_rate": h[3, :n, b].copy(), "z": np.ascontiguousarray(zh[:n, :, b].T)})
+                    "cog_rate": h[3, :n, b].copy(), "z": np.ascontiguousarray(zh[:n, :, b].T), "status": int(sth[b])})
     return res
 
 

@@ -5,6 +5,14 @@ optional ``smooth``; outputs ``{prefix}_{id}_predictions.txt``, ``_variances.txt
 ``_dts.txt``, ``original_{id}_track.txt`` and, with ``-rts``, ``_predictions_smoothed.txt`` / ``_variances_smoothed.txt``,
 all written with ``np.savetxt``.  The filter and smoother run on the GPU; several comma-separated ship ids are packed
 into one batched launch.
+
+Opt-in keys of ``input.json`` beyond the reference's (absent = the reference's behaviour):
+  ``"robust": true``      Mahalanobis outlier rejection in every update -- the reference's ``check_robustness``
+                          (kalman_filters/unscented.py:353-387), whose call site it ships commented out (:228); BASELINE.json
+                          configs[3] runs with it on
+  ``"chi_alpha": 50.0``   its threshold (the reference hard-codes 50, unscented.py:357)
+  ``"geodesy": "sphere"`` speed / course over ground from ``haversine_formula`` / ``heading`` (utils.py:75-147) instead of
+                          the WGS84 pair ``ShipTrack`` defaults to
 """
 from __future__ import annotations
 
@@ -18,7 +26,7 @@ import numpy as np
 from ..kalman_filters.non_linear_process import geodetic_dynamics
 from ..kalman_filters.unscented import UnscentedKalmanFilter
 from ..ship_track import ShipTrack
-from ..utils import generate_dts, smooth
+from ..utils import generate_dts, geographiclib_distance, geographiclib_heading, haversine_formula, heading, smooth
 from .argument_parser import __version__, create_parser
 from .json_loader import load_input_json
 
@@ -71,9 +79,26 @@ def get_input_settings(settings: dict) -> Tuple:
     return dim, dt, nsteps, H, Q, R, P, smooth_control
 
 
-def _prepare_track(args, ship_id, smooth_control):
+def get_optional_settings(settings: dict) -> Tuple[bool, float, str]:
+    """(robust, chi_alpha, geodesy): the opt-in keys this CLI adds to the reference's input.json (module docstring)."""
+    robust = settings.get("robust", False)
+    if not isinstance(robust, bool):
+        raise ValueError(f"'robust' must be true or false, got {robust!r}")
+    chi_alpha = float(settings.get("chi_alpha", 50.0))
+    if not chi_alpha > 0.0:
+        raise ValueError(f"'chi_alpha' must be positive, got {chi_alpha!r}")
+    geodesy = settings.get("geodesy", "wgs84")
+    if geodesy not in ("wgs84", "sphere"):
+        raise ValueError(f"'geodesy' must be \"wgs84\" or \"sphere\", got {geodesy!r}")
+    return robust, chi_alpha, geodesy
+
+
+def _prepare_track(args, ship_id, smooth_control, geodesy="wgs84"):
     """ShipTrack -> measurements, rates and prior exactly as main_cli.py:89-109 does."""
-    ship_track = ShipTrack()
+    if geodesy == "sphere":
+        ship_track = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    else:
+        ship_track = ShipTrack(calc_distance_func=geographiclib_distance, calc_heading_func=geographiclib_heading)
     ship_track.read_csv(args.track_file, ship_id=ship_id, id_col=args.id_col, lat_col=args.lat_id, lon_col=args.lon_id,
                         reverse=bool(args.reverse))
     if smooth_control not in [-1, 0, 1, None]:
@@ -115,11 +140,12 @@ def track_estimator(argv=None):
     logger.info(f"Reading input JSON from '{args.input_file}'...")
     settings = load_input_json(args.input_file)
     dim, dt, nsteps, H, Q, R, P, smooth_control = get_input_settings(settings)
+    robust, chi_alpha, geodesy = get_optional_settings(settings)
     substeps = nsteps if dt in [-1, 0, None] else 1  # a positive constant dt is ignored, like main_cli.py:114-120
 
     ship_ids = [s for s in str(args.ship_id).split(",") if s] if "," in str(args.ship_id) else [args.ship_id]
-    if len(ship_ids) == 1:
-        ship_track, x0 = _prepare_track(args, ship_ids[0], smooth_control)
+    if len(ship_ids) == 1 and not robust:
+        ship_track, x0 = _prepare_track(args, ship_ids[0], smooth_control, geodesy)
         dt_array = generate_dts(ship_track.dts, substeps)
         logger.info("Running the Unscented Kalman Filter.")
         ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
@@ -135,15 +161,17 @@ def track_estimator(argv=None):
 
         tracks, x0s, dts = [], [], []
         for sid in ship_ids:
-            st, x0 = _prepare_track(args, sid, smooth_control)
+            st, x0 = _prepare_track(args, sid, smooth_control, geodesy)
             tracks.append(st)
             x0s.append(x0[:, 0])
             dts.append(generate_dts(st.dts, substeps))
-        logger.info(f"Running the Unscented Kalman Filter on {len(tracks)} tracks in one batch.")
+        logger.info(f"Running the Unscented Kalman Filter on {len(tracks)} track(s) in one batch"
+                    + (f", Mahalanobis outlier rejection on (chi_alpha = {chi_alpha:g})." if robust else "."))
         noise = None
         if not args.no_noise:
             noise = [batch.draw_reference_noise(np.asarray(Q), np.asarray(R), d, st.dts) for d, st in zip(dts, tracks)]
         hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, np.asarray(P, dtype=np.float64), noise=noise)
+        hb.robust, hb.chi_alpha = robust, chi_alpha
         out = batch.run_batch(hb, smooth=args.apply_rts_smoother)
         logger.info(f"Writing outputs with prefix '{args.output_prefix}'.")
         for b, sid in enumerate(ship_ids):

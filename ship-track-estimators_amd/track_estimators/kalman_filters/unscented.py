@@ -156,7 +156,8 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         x, P = _up(torch, dev, self.x, (4, 1)), _up(torch, dev, self.P, (16, 1))
         d, a, b = (_up(torch, dev, v, (1,)) for v in (dt, sr, cr))
         nz = _up(torch, dev, noise, (4, 1))
-        Q = _batch._as44(self.Q, "Q")
+        Q = _batch._as44(self.Q, "Q", True)
+        _batch.require_symmetric(np.asarray(self.P, dtype=np.float64).reshape(4, 4), "P")
         xo, Po = torch.empty_like(x), torch.empty_like(P)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         binding.check(lib.ste_ukf_predict_f64(1, x.data_ptr(), P.data_ptr(), d.data_ptr(), a.data_ptr(), b.data_ptr(),
@@ -176,7 +177,8 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         torch, dev = _dev()
         x, P = _up(torch, dev, self.x, (4, 1)), _up(torch, dev, self.P, (16, 1))
         zt, nz = _up(torch, dev, zz, (4, 1)), _up(torch, dev, noise, (4, 1))
-        H, R = _batch._as44(self.H, "H"), _batch._as44(self.R, "R")
+        H, R = _batch._as44(self.H, "H"), _batch._as44(self.R, "R", True)
+        _batch.require_symmetric(np.asarray(self.P, dtype=np.float64).reshape(4, 4), "P")
         xo, Po = torch.empty_like(x), torch.empty_like(P)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         binding.check(lib.ste_ukf_update_f64(1, x.data_ptr(), P.data_ptr(), zt.data_ptr(), nz.data_ptr(), H.ctypes.data,
@@ -244,8 +246,9 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         lib = binding.require_gpu()
         torch, dev = _dev()
         m = fwd_means.reshape(nrows, 4)
+        _batch.require_symmetric(np.asarray(fwd_vars, dtype=np.float64).reshape(nrows, 4, 4), "fwd_vars")
         hb = _batch.HostBatch(
-            B=1, Nmax=N, Tmax=1, H=_batch._as44(self.H, "H"), Q=_batch._as44(self.Q, "Q"), R=_batch._as44(self.R, "R"),
+            B=1, Nmax=N, Tmax=1, H=_batch._as44(self.H, "H"), Q=_batch._as44(self.Q, "Q", True), R=_batch._as44(self.R, "R", True),
             nsteps=np.array([N], dtype=np.int32), x0=np.ascontiguousarray(m[0].reshape(4, 1)),
             P0=np.ascontiguousarray(np.asarray(fwd_vars[0], dtype=np.float64).reshape(16)),
             dt=np.ascontiguousarray(dt[:N].reshape(N, 1)),
@@ -278,7 +281,8 @@ class UnscentedKalmanFilter(KalmanFilterBase):
         torch, dev = _dev()
         x, Pm = _up(torch, dev, self.x, (4, 1)), _up(torch, dev, P, (16, 1))
         zt = _up(torch, dev, np.asarray(z, dtype=np.float64).reshape(-1), (4, 1))
-        H, Rm = _batch._as44(self.H, "H"), _batch._as44(R, "R")
+        H, Rm = _batch._as44(self.H, "H"), _batch._as44(R, "R", True)
+        _batch.require_symmetric(np.asarray(P, dtype=np.float64).reshape(4, 4), "P")
         g, d = torch.empty((1,), dtype=torch.float64, device=dev), torch.empty((1,), dtype=torch.float64, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         binding.check(lib.ste_ukf_robust_terms_f64(1, x.data_ptr(), Pm.data_ptr(), zt.data_ptr(), H.ctypes.data,

@@ -12,6 +12,7 @@ antipodal pairs.
 from __future__ import annotations
 
 import math
+import warnings
 from typing import List, Union
 
 import numpy as np
@@ -41,6 +42,7 @@ def _wgs84_inverse(lat1, lon1, lat2, lon2):
     U2 = math.atan((1.0 - f) * math.tan(phi2))
     sU1, cU1, sU2, cU2 = math.sin(U1), math.cos(U1), math.sin(U2), math.cos(U2)
     lam = L
+    done = False
     for _ in range(200):
         sl, cl = math.sin(lam), math.cos(lam)
         sin_sigma = math.hypot(cU2 * sl, cU1 * sU2 - sU1 * cU2 * cl)
@@ -58,6 +60,12 @@ def _wgs84_inverse(lat1, lon1, lat2, lon2):
         lam = lam_new
         if done:
             break
+    if not done:
+        # the fixed point does not contract for nearly antipodal points; Karney's solver (geographiclib, what the
+        # reference calls) has no such limit.  The last iterate is returned, loudly.
+        warnings.warn(f"Vincenty's inverse iteration did not converge for ({lat1}, {lon1}) -> ({lat2}, {lon2}) (nearly "
+                      "antipodal points); distance and azimuth are approximate.  Install geographiclib for Karney's "
+                      "algorithm.", RuntimeWarning, stacklevel=3)
     sl, cl = math.sin(lam), math.cos(lam)
     u2 = cos2_alpha * (a * a - b * b) / (b * b)
     A = 1.0 + u2 / 16384.0 * (4096.0 + u2 * (-768.0 + u2 * (320.0 - 175.0 * u2)))

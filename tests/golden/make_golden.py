@@ -503,6 +503,76 @@ def smooth_case():
                 cog_rate=st.cog_rate, smooth_even=smooth(np.arange(7.0) ** 2, 4))
 
 
+def savgol_case():
+    """The compute part of examples/example_ukf_rts_smoother_savgol.py:15-86 as written: ship 01205070 read in reverse,
+    COG / SOG through scipy's Savitzky-Golay filter (windows 20 / 4, orders 4 / 2), the example's matrices, two
+    sub-steps, UKF then RTS smoother.  Harness changes only: the sphere pair is injected (geographiclib is absent here)
+    and the global noise draws are zeroed."""
+    from scipy.signal import savgol_filter
+
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv(csv_file="/root/reference/data/historical_ships/historical_ship_data.csv", ship_id="01205070", id_col="id",
+                lat_col="lat", lon_col="lon", reverse=True)
+    st.calculate_cog()
+    st.calculate_sog()
+    raw_sog, raw_cog = st.sog.copy(), st.cog.copy()
+    st.sog = savgol_filter(st.sog, 20, 4)
+    st.cog = savgol_filter(st.cog, 4, 2)
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    H = np.diag([1, 1, 0, 0])
+    R = np.diag([0.001, 0.001, 0, 0])
+    Q = np.diag([1e-3, 1e-3, 1e-6, 1e-6])
+    P = np.diag([1.0, 1.0, 1.0, 1.0])
+    res = run_reference(st, H, Q, R, P, 2, "zero")
+    res.update(raw_sog=raw_sog, raw_cog=raw_cog, sog=st.sog, cog=st.cog, sog_rate=st.sog_rate, cog_rate=st.cog_rate, z=z,
+               dts=st.dts, lon=st.lon, lat=st.lat, H=H.astype(np.float64), Q=Q, R=R, P0=P)
+    print(f"savgol example: T={len(st.lon)} N={len(res['dt'])}")
+    return res
+
+
+def illcond_cases():
+    """Smoother gains on ill-conditioned P_b: tiny process noise, a prior that knows speed and heading
+    far better than position, long steps.  cond(P_b) of the reference's own smoother pass is recorded per case (its P_b is
+    recomputed here from the reference's filtered history with the reference's own calls) and spans ~1e4 ... 1e11, i.e.
+    both sides of the factorisation's pivot threshold (kLdlPivotTol)."""
+    H = np.diag([1, 1, 0, 0])
+    plan = [
+        # (P0 diagonal, Q diagonal, R position variance, gap hours, substeps, seed)
+        ([1.0, 1.0, 1e-3, 1e-2], [1e-6, 1e-6, 1e-9, 1e-8], 1e-2, 3.0, 2, 21),
+        ([1.0, 1.0, 1e-5, 1e-4], [1e-8, 1e-8, 1e-11, 1e-10], 1e-2, 6.0, 2, 22),
+        ([1.0, 1.0, 1e-7, 1e-6], [1e-9, 1e-9, 1e-13, 1e-12], 1e-3, 6.0, 1, 23),
+        ([10.0, 10.0, 1e-8, 1e-8], [1e-10, 1e-10, 1e-14, 1e-14], 1e-3, 12.0, 1, 24),
+        ([100.0, 100.0, 1e-9, 1e-9], [0.0, 0.0, 1e-15, 1e-15], 1e-2, 12.0, 1, 25),
+    ]
+    cases = []
+    for p0, q, r, gap, s, seed in plan:
+        P, Q, R = np.diag(p0), np.diag(q), np.diag([r, r, 0, 0])
+        sb = synthetic.make_batch(1, nobs=41, gap_h=gap, seed0=seed)
+        st = ship_track_from_arrays(sb, 0)
+        res = run_reference(st, H, Q, R, P, s, "zero")
+        # cond(P_b) along the reference's smoother pass: its own fan / process model / weights on its own filtered history
+        ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=res["x0"].reshape(-1, 1), non_linear_process=geodetic_dynamics)
+        ukf.compute_weights()
+        rep = int((len(res["dt"]) + 1) / len(sb.dts[0]))
+        sr, cr = np.repeat(sb.sog_rate[0], rep), np.repeat(sb.cog_rate[0], rep)
+        conds = []
+        for k in range(len(res["dt"])):
+            xk, Pk = res["means"][k].reshape(-1, 1), res["covs"][k]
+            sig = ukf.compute_sigma_points(xk, Pk).copy()
+            for j in range(sig.shape[1]):
+                sig[:, j] = geodetic_dynamics(sig[:, j], c=None, dt=res["dt"][k], sog_rate=sr[k], cog_rate=cr[k])
+            S = sig - xk
+            Pb = S @ ukf.weights @ S.T + Q
+            conds.append(np.linalg.cond(Pb))
+        res.update(mode="zero", substeps=s, H=H.astype(np.float64), Q=Q, R=R, P0=P, dts=sb.dts[0], z=sb.z[0], sog=sb.sog[0],
+                   cog=sb.cog[0], sog_rate=sb.sog_rate[0], cog_rate=sb.cog_rate[0], cond_pb=np.asarray(conds))
+        cases.append(res)
+        print(f"illcond seed={seed}: N={len(res['dt'])} cond(P_b) {min(conds):.2e} .. {max(conds):.2e}")
+    return cases
+
+
 def two_runs_case():
     """A second ``run`` on the same filter object appends to the history and keeps the running time
     (kalman_filter.py:22-31,98): the update index restarts at 0 while ``self.time`` continues, so the float-equality
@@ -674,6 +744,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "track_prep.npz"), **prep_cases())
     np.savez_compressed(os.path.join(HERE, "batch_examples.npz"), **example_cases())
     np.savez_compressed(os.path.join(HERE, "cli_smooth.npz"), **smooth_case())
+    np.savez_compressed(os.path.join(HERE, "savgol_example.npz"), **savgol_case())
+    np.savez_compressed(os.path.join(HERE, "ukf_illcond.npz"), **pack_cases(illcond_cases()))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
@@ -681,7 +753,8 @@ def main():
 
 SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
               "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz"),
-              "smooth": (smooth_case, "cli_smooth.npz")}
+              "smooth": (smooth_case, "cli_smooth.npz"), "savgol": (savgol_case, "savgol_example.npz"),
+              "illcond": (lambda: pack_cases(illcond_cases()), "ukf_illcond.npz")}
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only: python make_golden.py robust prep ...

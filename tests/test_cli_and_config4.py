@@ -339,3 +339,53 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_cli_optional_keys_parse_and_validate():
+    from track_estimators.cli.main_cli import get_optional_settings
+
+    assert get_optional_settings({}) == (False, 50.0, "wgs84")  # absent = the reference's behaviour
+    assert get_optional_settings({"robust": True, "chi_alpha": 30, "geodesy": "sphere"}) == (True, 30.0, "sphere")
+    for bad in ({"robust": "yes"}, {"chi_alpha": 0}, {"geodesy": "flat"}):
+        with pytest.raises(ValueError):
+            get_optional_settings(bad)
+
+
+@pytest.mark.gpu
+def test_cli_config4_robust_through_the_entry_point(tmp_path, monkeypatch):
+    """BASELINE configs[3] through the reference's own entry point: `track_estimator` on a modern_ships id with
+    `"robust": true` in input.json (plus `"geodesy": "sphere"`, the distance / heading pair the fixture's reference run
+    used -- geographiclib is on neither box) must write the predictions and smoothed predictions of the reference run with
+    its check_robustness call site enabled (tests/golden/modern_ships_robust.npz)."""
+    from track_estimators.cli.main_cli import track_estimator
+
+    gr = np.load(os.path.join(GOLDEN, "modern_ships_robust.npz"))
+    monkeypatch.chdir(tmp_path)
+    with gzip.open(os.path.join(GOLDEN, "data", "modern_ship_data.csv.gz"), "rb") as src, open("modern.csv", "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    with open("input.json", "w") as f:
+        json.dump({"dim": 4, "H": [1, 1, 0, 0], "R": [0.25, 0.25, 0, 0], "Q": [1e-4, 1e-4, 1e-6, 1e-6], "P": [1.0, 1.0, 1.0, 1.0],
+                   "dt": -1, "nsteps": 2, "robust": True, "chi_alpha": 50.0, "geodesy": "sphere"}, f)
+    with np.errstate(all="ignore"):
+        track_estimator(["-t", "modern.csv", "-s", "WCE5063", "-ic", "id", "-lat", "lat", "-lon", "lon", "-rts", "--no-noise"])
+    rows = gr["WCE5063_rows"]
+    for fname, key in (("output_WCE5063_predictions.txt", "WCE5063_means"),
+                       ("output_WCE5063_predictions_smoothed.txt", "WCE5063_means_smoothed")):
+        got = np.loadtxt(fname)[rows]
+        ref = gr[key]
+        assert float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3))) < 1e-6, fname
+    var = np.loadtxt("output_WCE5063_variances_smoothed.txt")[rows]
+    refv = np.diagonal(gr["WCE5063_covs_smoothed"], axis1=1, axis2=2)
+    assert float(np.max(np.abs(var - refv) / np.max(np.abs(gr["WCE5063_covs_smoothed"]), axis=(-1, -2))[:, None])) < 1e-5
+    # without the key the same command is the plain filter: a different answer on this ship (38 419 rescaled updates)
+    with open("input.json") as f:
+        cfg = json.load(f)
+    cfg.pop("robust")
+    os.makedirs("plain", exist_ok=True)
+    with open("plain/input.json", "w") as f:
+        json.dump(cfg, f)
+    monkeypatch.chdir(tmp_path / "plain")
+    with np.errstate(all="ignore"):
+        track_estimator(["-t", "../modern.csv", "-s", "WCE5063", "-ic", "id", "-lat", "lat", "-lon", "lon", "--no-noise"])
+    plain = np.loadtxt("output_WCE5063_predictions.txt")[rows]
+    assert np.abs(plain - gr["WCE5063_means"]).max() > 1e-3

@@ -127,3 +127,45 @@ def test_cli_example_run_sh_command_line(tmp_path):
     np.testing.assert_allclose(pred[0], [-30.5, -0.5, 14.578418614021368, 198.52495095065817], rtol=1e-11)
     for suffix in ("variances", "dts", "predictions_smoothed", "variances_smoothed"):
         assert (work / f"output_01203823_{suffix}.txt").exists(), suffix
+
+
+@pytest.mark.gpu
+def test_savgol_example_vs_reference_example():
+    """examples/example_ukf_rts_smoother_savgol.py against the reference script of the same name run as written
+    (tests/golden/savgol_example.npz, make_golden.savgol_case: ship 01205070 in reverse, Savitzky-Golay on SOG / COG,
+    sphere pair injected, noise zeroed): the smoothed inputs exactly, the filtered and smoothed histories to the parity
+    bound."""
+    g = np.load(os.path.join(GOLDEN, "savgol_example.npz"))
+    ex = _load_example("example_ukf_rts_smoother_savgol")
+    res = ex.run(CSV, out_path=None, sphere=True, inject_noise=False)
+    for key in ("sog", "cog", "z"):
+        np.testing.assert_allclose(res[key], g[key], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(res["dt"], g["dt"]) and len(res["dt"]) == 66
+    for key in ("means", "means_smoothed"):
+        err = np.max(np.abs(res[key] - g[key]) / np.maximum(np.abs(g[key]), 1e-3))
+        assert err < 1e-6, (key, err)
+    for key in ("covs", "covs_smoothed"):
+        err = np.max(np.abs(res[key] - g[key]) / np.max(np.abs(g[key]), axis=(-1, -2), keepdims=True))
+        assert err < 1e-5, (key, err)
+
+
+def test_savgol_example_host_preparation_vs_reference():
+    """CPU half of the same: read_csv(reverse=True) + calculate_cog / calculate_sog + savgol_filter + measurements and
+    rates of the host ShipTrack reproduce the reference's arrays exactly (no GPU needed up to the filter)."""
+    from scipy.signal import savgol_filter
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import haversine_formula, heading
+
+    g = np.load(os.path.join(GOLDEN, "savgol_example.npz"))
+    st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+    st.read_csv(csv_file=CSV, ship_id="01205070", id_col="id", lat_col="lat", lon_col="lon", reverse=True)
+    st.calculate_cog()
+    st.calculate_sog()
+    assert np.array_equal(st.sog, g["raw_sog"]) and np.array_equal(st.cog, g["raw_cog"])
+    st.sog = savgol_filter(st.sog, 20, 4)
+    st.cog = savgol_filter(st.cog, 4, 2)
+    z = st.get_measurements(include_sog=True, include_cog=True)
+    st.calculate_cog_rate()
+    st.calculate_sog_rate()
+    assert np.array_equal(z, g["z"]) and np.array_equal(st.dts, g["dts"])
+    assert np.array_equal(st.sog_rate, g["sog_rate"]) and np.array_equal(st.cog_rate, g["cog_rate"])

@@ -191,3 +191,50 @@ def test_cli_presmoothing_vs_reference():
         np.testing.assert_array_equal(getattr(st, k), g[k], err_msg=k)
     np.testing.assert_array_equal(z, g["z"])
     np.testing.assert_array_equal(smooth(np.arange(7.0) ** 2, 4), g["smooth_even"])
+
+
+def test_non_symmetric_covariances_are_refused():
+    """Q, R, P0 (and every covariance handed to the drop-in class) must be symmetric: the kernels use a symmetric square
+    root and an eigenvalue pseudo-inverse, the reference calls sqrtm / pinv on whatever it gets, and on a non-symmetric
+    matrix those are different computations -- so the host refuses instead of silently symmetrising."""
+    import types
+
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(3, nobs=6, gap_h=1.0, seed0=1)
+    assert batch.pack_uniform(sb, 2, H, Q, R, P0).B == 3  # the regular matrices pass
+    skew = np.zeros((4, 4))
+    skew[0, 1], skew[1, 0] = 1e-3, -1e-3
+    for name in ("Q", "R", "P0"):
+        kw = dict(H=H, Q=Q, R=R, P0=P0)
+        kw[name] = kw[name] + skew
+        with pytest.raises(ValueError, match=f"{name} must be symmetric"):
+            batch.pack_uniform(sb, 2, **kw)
+    tr = [types.SimpleNamespace(z=sb.z[b], dts=sb.dts[b], sog_rate=sb.sog_rate[b], cog_rate=sb.cog_rate[b]) for b in range(3)]
+    dts = [np.repeat(sb.dts[b] / 2, 2) for b in range(3)]
+    x0s = [sb.z[b][:, 0] for b in range(3)]
+    with pytest.raises(ValueError, match="P0 must be symmetric"):
+        batch.pack_tracks(tr, dts, x0s, H, Q, R, np.stack([P0, P0 + skew, P0]))
+    # asymmetry at rounding level is what arithmetic leaves behind: accepted
+    tiny = np.zeros((4, 4))
+    tiny[0, 1] = 1e-17
+    assert batch.pack_uniform(sb, 2, H, Q + tiny, R, P0).B == 3
+    # non-finite entries are not a symmetry question (config 4's data produces them downstream): no ValueError here
+    batch.require_symmetric(np.full((4, 4), np.nan), "P")
+
+
+def test_vincenty_non_convergence_is_loud():
+    """The WGS84 fallback (Vincenty) does not converge for nearly antipodal points, where the reference's geographiclib
+    (Karney) still does: the host helper warns instead of returning the last iterate silently (missing 3)."""
+    import warnings
+
+    from track_estimators import utils
+
+    if utils._HAVE_GEOGRAPHICLIB:
+        pytest.skip("geographiclib present: Karney's solver, no Vincenty fallback")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert 0 < utils.geographiclib_distance(-30.5, -0.5, 20.0, 40.0) < 2.1e4  # an ordinary leg: silent
+    with pytest.warns(RuntimeWarning, match="did not converge"):
+        utils.geographiclib_distance(0.0, 0.0, 179.7, 0.2)

@@ -166,3 +166,22 @@ def test_prep_wgs84_unpinned_feeds_filter_end_to_end():
         n = outs[0]["nsteps"][b] + 1
         a, c = outs[0]["means_smoothed"][b, :n], outs[1]["means_smoothed"][b, :n]
         assert np.max(np.abs(a - c) / np.maximum(np.abs(a), 1e-12)) < 1e-6
+
+
+def test_prep_wgs84_flags_legs_vincenty_cannot_solve():
+    """A nearly antipodal leg (where Vincenty's iteration does not contract, but the reference's geographiclib would still
+    answer): the device sets STE_PREP_STATUS_NOCONV for that track only, the Python wrapper warns and hands the bit back;
+    the sphere model never flags."""
+    lons = [np.array([0.0, 1.0, 2.0]), np.array([0.0, 179.7, 179.9]), np.array([10.0, 10.5, 11.0])]
+    lats = [np.array([0.0, 1.0, 2.0]), np.array([0.0, 0.2, 0.4]), np.array([50.0, 50.5, 51.0])]
+    gaps = [np.ones(2), np.ones(2), np.ones(2)]
+    with pytest.warns(RuntimeWarning, match=r"track\(s\) \[1\]"):
+        res = batch.prepare_observations(lons, lats, gaps, model="wgs84")
+    assert [r["status"] for r in res] == [0, 1, 0]
+    assert np.all(np.isfinite(res[0]["sog"])) and np.all(np.isfinite(res[2]["sog"]))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        res = batch.prepare_observations(lons, lats, gaps, model="sphere")
+    assert [r["status"] for r in res] == [0, 0, 0]
