@@ -52,7 +52,7 @@ BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mea
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
 FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
 # rocprofv3 PMC summary of this command for the current kernel generation (see profiles/README.md for the passes)
-COUNTERS_CSV = os.path.join(ROOT, "profiles", "r02_counters_per_track_step.csv")
+COUNTERS_CSV = os.path.join(ROOT, "profiles", "r03_counters_per_track_step.csv")
 
 
 def load_counters():

@@ -1,12 +1,12 @@
 // ste_kernels.hip — batched UKF forward pass and unscented RTS smoother for gfx950 (MI355X), plus the C ABI of
-// include/ste.h.  fp64 throughout; no MFMA (4x4 contractions), no LDS: the whole per-track state lives in VGPRs.
+// include/ste.h.  fp64 throughout; no MFMA (4x4 contractions); the whole per-track state lives in VGPRs and no kernel of
+// this file uses LDS (the quad forward kernel exchanges rows by DPP).
 //
 // Kernels:
-//   ukf_forward_q4 / ukf_forward_l1      forward filter, one DPP quad or one lane per track (chosen by batch size);
-//                                        with rts_work they also emit the smoother's x_b, P_b and cross-covariance D
-//   urtss_smooth_wg                      smoother from those rows: per 64 tracks, producer waves turn D into the gain
-//                                        K = D pinv(P_b) one block of steps ahead and hand it through LDS to the wave
-//                                        that runs the sequential recurrence
+//   ukf_forward_l1 / ukf_forward_q4      forward filter, one lane or one DPP quad per track (chosen by batch size or by
+//                                        flag); with rts_work they also leave the smoother's cross-covariance D and,
+//                                        where it does not follow from the history, its x_b and P_b
+//   urtss_recur_l1                       smoother from those rows, one lane per track: gain K = D pinv(P_b), recurrence
 //   urtss_backward_l1                    stand-alone smoother that recomputes everything (rts_work == NULL)
 //   predict / update / robust_terms / geodetic / sigma_points kernels   single-step API parity
 // All per-step inputs/outputs are SoA with the track index fastest, so a wave's accesses are contiguous runs.
@@ -306,7 +306,14 @@ __device__ __forceinline__ void propagate_points(const double (&x)[4], const dou
         sig[5 + i][2] = ptm[2] + du;
         sig[5 + i][3] = fma(ptm[3] * kDeg2Rad, kRad2Deg, da);
     }
-    if (__builtin_expect(__any(!ok), 0)) {
+    double fin = dt + sr + cr;  // non-finite lanes end in NaN on either path: they do not ask for the slow one
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        fin += x[r];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) fin += T[r][c];
+    }
+    if (__builtin_expect(__any(!ok && fin * 0.0 == 0.0), 0)) {
         // Out of line, through copies: the branching version calls the device library (Payne-Hanek sincos, atan2, asin) and
         // is ~55 KB of code; inlined it tripled this kernel's size and register pressure.  Its arguments are address-taken,
         // so they are private copies here and the hot path's arrays stay in registers.
@@ -563,9 +570,18 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
         fan_pair<3>(x, T, g, lonp, latp, lonm, latm, ok);
         moments_add<3, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
     }
-    if (__builtin_expect(__any(!ok), 0)) {
-        // Some lane left the validity range of the branch-free transcendentals (a pole, a step of tens of degrees,
-        // non-finite data): the whole fan again with the branching version (device-library sincos / atan2 / asin, out
+    // A lane whose inputs are already non-finite fails every range test, but its outcome is NaN on either path: it must not
+    // send its whole wave through the slow one (BASELINE configs[3]: five of seven ships go non-finite early -- duplicate
+    // timestamps -- and dragged the two healthy ones along at a tenth of the speed, step after step).
+    double fin = dt + sr + cr;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) fin += x[c];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) fin += T[e];
+    const bool finite_in = fin * 0.0 == 0.0;
+    if (__builtin_expect(__any(!ok && finite_in), 0)) {
+        // Some lane left the validity range of the branch-free transcendentals (a pole, a step of tens of degrees):
+        // the whole fan again with the branching version (device-library sincos / atan2 / asin, out
         // of line, through copies so that the hot path's arrays stay in registers), same formulas for the lanes that
         // were fine, then the same moment sums.
         double xc[4], Tc[4][4], s0c[9][4], sc[9][4];

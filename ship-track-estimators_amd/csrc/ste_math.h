@@ -1,7 +1,7 @@
 // ste_math.h — per-lane fp64 building blocks of the UKF / URTSS kernels (gfx950).
 //
 // Everything here works on small fixed-size arrays whose indices are compile-time constants after unrolling, so the
-// whole filter state lives in VGPRs (no scratch, no LDS).  Reference semantics being reproduced are cited per function
+// whole filter state lives in VGPRs (no LDS; scratch only on the rare out-of-line paths).  Reference semantics being reproduced are cited per function
 // (paths relative to /root/reference/src/track_estimators/kalman_filters/).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -447,7 +447,10 @@ __device__ __forceinline__ void quad_propagate(const double (&x)[4], const doubl
     const double vcd[3] = {cd0, fma(cd0, c_d[2], -d4), fma(cd0, c_d[2], d4)};
     double lon_o[3], lat_o[3];
     geodetic_finish_n<3>(lon_r, lat_r, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
-    if (__builtin_expect(__any(!ok), 0)) {
+    // a lane whose inputs are already non-finite fails every range test but ends in NaN on either path: it must not send
+    // its wave through the slow one (see lane_predict)
+    const double fin = (dt + sr + cr + x[0] + x[1] + x[2] + x[3] + Tn[0] + Tn[1] + Tn[2] + Tn[3]) * 0.0;
+    if (__builtin_expect(__any(!ok && fin == 0.0), 0)) {
         quad_propagate_branching(x, Tn, dt, sr, cr, s0, sp, sm);
         return;
     }
