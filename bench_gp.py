@@ -19,6 +19,20 @@ for p in (ROOT, os.path.join(ROOT, "ship-track-estimators_amd")):
 
 import numpy as np  # noqa: E402
 
+
+def host_core_share() -> int:
+    """Cores this process may really use (what BLAS threads can run on): the affinity mask, cut by the cgroup CPU quota when
+    there is one, and by 16 -- the CPU share of a one-GPU box -- when the quota is not visible.  os.cpu_count() reports the
+    machine (256 on the GPU box), not the share."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (= vector peak on CDNA4)
 
 
@@ -74,7 +88,7 @@ def measure_fit(tracks=64, nobs=2000, restarts=15, cpu=True):
         ref = GaussianProcessRegressor(kernel=1.0 * RBF(1.0) + WhiteKernel(0.5), n_restarts_optimizer=restarts,
                                        random_state=0).fit(xs[0].reshape(-1, 1), ys[0])
         out["cpu_reference"] = {
-            "seconds_per_track": time.perf_counter() - t0, "cores": os.cpu_count(), "kind": "reference",
+            "seconds_per_track": time.perf_counter() - t0, "cores": host_core_share(), "kind": "reference",
             "sample": "scikit-learn GaussianProcessRegressor(n_restarts_optimizer, random_state=0).fit on track 0, the call "
                       "the reference's GPRegression.fit makes (gaussian_process.py:63-66)",
             "lml_rel_diff_track0": float(abs(best[0] - ref.log_marginal_likelihood_value_)
@@ -124,9 +138,9 @@ def measure(tracks=1000, nobs=2000, evals=3, cpu_evals=2, fit=False):
         for k in range(args.cpu_evals):
             l, g, _, _ = gpo.lml_and_grad(theta[k], xs[k], ys[k])
         dt = (time.perf_counter() - t0) / args.cpu_evals
-        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "track-objectives/s", "cores": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "track-objectives/s", "cores": host_core_share(), "kind": "port",
                                "sample": f"{args.cpu_evals} objective evaluations at n={n} (oracle/gp_oracle.py: SciPy "
-                                         "LAPACK cholesky/cho_solve, the same calls scikit-learn makes), BLAS threads = all",
+                                         "LAPACK cholesky/cho_solve, the same calls scikit-learn makes), BLAS threads = all it is given",
                                "gpu_vs_oracle_rel_err_lml": float(abs(lml[args.cpu_evals - 1] - l) / abs(l))}
     if args.fit:
         from track_estimators.gaussian_processes import gaussian_process as gpm
@@ -155,7 +169,7 @@ def measure(tracks=1000, nobs=2000, evals=3, cpu_evals=2, fit=False):
         ref = GaussianProcessRegressor(kernel=1.0 * RBF(1.0) + WhiteKernel(0.5)).fit(xs[0].reshape(-1, 1), ys[0])
         t_ref = time.perf_counter() - t0
         out["fit"]["cpu_reference"] = {
-            "seconds_per_track": t_ref, "cores": os.cpu_count(), "kind": "reference",
+            "seconds_per_track": t_ref, "cores": host_core_share(), "kind": "reference",
             "sample": "scikit-learn GaussianProcessRegressor.fit on track 0, the call the reference's GPRegression.fit "
                       "makes (gaussian_process.py:63-66)",
             "lml_rel_diff_track0": float(abs(best[0] - ref.log_marginal_likelihood_value_)

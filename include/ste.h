@@ -216,12 +216,17 @@ int ste_sigma_points_generic_f64(int32_t n, int64_t count, const double* x, cons
  * the same HBM channel when 64 * ceil(nmax / 64) is a power of two); all buffers are caller-owned device memory.
  * ------------------------------------------------------------------------------------------------------------- */
 #define STE_GP_LD_PAD 16
+#define STE_GP_INVERSE_AUTO 0 /* column order (one workgroup per matrix) when B >= 128, else row order (nb workgroups per matrix) */
+#define STE_GP_INVERSE_ROWS 1
+#define STE_GP_INVERSE_COLS 2
 
 typedef struct ste_gp_batch_f64 {
     int32_t B;     /* number of tracks */
     int32_t nmax;  /* padded number of observations */
     int32_t nout;  /* output columns of y (2: lon, lat) */
-    int32_t reserved;
+    int32_t inverse_order; /* which kernel forms U = L^-T: STE_GP_INVERSE_AUTO (0: by B, see below), _ROWS (1), _COLS (2).  The two
+                              sum in different orders, so objectives that must agree bit for bit (a track's first start and
+                              its restarts in a replicated batch) have to name the same one */
     double jitter; /* added to the diagonal of K (GaussianProcessRegressor alpha, 1e-10) */
     const int32_t* n;    /* [B] observations per track */
     const double* x;     /* [B][nmax] */

@@ -51,6 +51,7 @@ struct GpParams {
     double* tr;     // [B][3][ntiles_max] per-tile partial sums of tr(K^-1 Krbf), tr(K^-1 (Krbf o D2)), tr(K^-1)
     int32_t* status;
     int store_kinv;
+    int inverse_cols;  // U = L^-T by gp_trtri_cols (else gp_trtri_rows)
     // Subset launches (ste_gp_lml_subset_f64): the grid covers `nslots` matrices and slot s works on matrix active[s];
     // without a list, slot s is matrix s and nslots == B.
     int nslots;
@@ -976,6 +977,10 @@ int gp_params(const ste_gp_batch_f64* b, stegp::GpParams* p) {
     p->tr = b->tr;
     p->status = b->status;
     p->store_kinv = 0;
+    if (b->inverse_order < STE_GP_INVERSE_AUTO || b->inverse_order > STE_GP_INVERSE_COLS)
+        return gp_fail("inverse_order must be STE_GP_INVERSE_AUTO, _ROWS or _COLS");
+    // AUTO: chosen by the size of the BATCH, not of a launch over a subset of it
+    p->inverse_cols = b->inverse_order == STE_GP_INVERSE_AUTO ? (b->B >= 128) : (b->inverse_order == STE_GP_INVERSE_COLS);
     p->nslots = b->B;
     p->active = nullptr;
     return STE_OK;
@@ -1018,10 +1023,10 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
     hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, ns), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(ns), dim3(256), 0, s, p);
-    // chosen by the size of the BATCH, not of this launch: a subset launch must leave the bits a full launch leaves
-    // (include/ste.h: "per-matrix results do not depend on which other matrices are listed"), and the two inverse kernels
-    // sum in different orders
-    if (p.B >= 128)
+    // which of the two inverse kernels runs is a property of the batch (gp_params), never of this launch: a subset launch
+    // must leave the bits a full launch leaves (include/ste.h: "per-matrix results do not depend on which other matrices are
+    // listed"), and the two kernels sum in different orders
+    if (p.inverse_cols)
         hipLaunchKernelGGL(stegp::gp_trtri_cols, dim3(ns), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(stegp::gp_trtri_rows, dim3(p.nb_max, ns), dim3(256), 0, s, p);

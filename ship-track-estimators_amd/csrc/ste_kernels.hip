@@ -489,13 +489,16 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
     int st = rst;
     {
         bool blk = true;  // S confined to its leading 2 x 2 block (exact zeros elsewhere), for every track of the wave
+        double fin = 0.0;
         STE_UNROLL
         for (int r = 0; r < 4; ++r) {
             STE_UNROLL
             for (int c = 0; c < 4; ++c) {
                 if (r >= 2 || c >= 2) blk = blk && (S[r][c] == 0.0);
+                fin += S[r][c];
             }
         }
+        blk = blk || !(fin * 0.0 == 0.0);  // a non-finite S is NaN on either route: no veto against the fast one
         if (__all(blk))
             sym_pinv4_block2(S, Si);
         else

@@ -262,8 +262,10 @@ __device__ __forceinline__ int quad_sym_pinv(const double (&Sn)[4], const QuadCt
     // is three quarters zeros.  Taken only when every track of the wave has that structure.
     {
         const int q = cx.q;
-        const bool blk = (q < 2) ? (Sn[2] == 0.0 && Sn[3] == 0.0)
-                                 : (Sn[0] == 0.0 && Sn[1] == 0.0 && Sn[2] == 0.0 && Sn[3] == 0.0);
+        // (a quad whose S is already non-finite does not veto the fast path for its wave: its result is NaN either way)
+        const bool fin = (Sn[0] + Sn[1] + Sn[2] + Sn[3]) * 0.0 == 0.0;
+        const bool blk = !fin || ((q < 2) ? (Sn[2] == 0.0 && Sn[3] == 0.0)
+                                          : (Sn[0] == 0.0 && Sn[1] == 0.0 && Sn[2] == 0.0 && Sn[3] == 0.0));
         if (__all(blk)) {
             const double a = bcast<0>(Sn[0]), d = bcast<1>(Sn[1]);
             const double b = 0.5 * (bcast<0>(Sn[1]) + bcast<1>(Sn[0]));

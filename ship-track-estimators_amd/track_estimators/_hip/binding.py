@@ -81,7 +81,7 @@ class SteGpBatchF64(C.Structure):
         ("B", C.c_int32),
         ("nmax", C.c_int32),
         ("nout", C.c_int32),
-        ("reserved", C.c_int32),
+        ("inverse_order", C.c_int32),
         ("jitter", C.c_double),
         ("n", _dp),
         ("x", _dp),
@@ -120,6 +120,7 @@ class StePrepBatchF64(C.Structure):
     ]
 
 
+STE_GP_INVERSE_AUTO, STE_GP_INVERSE_ROWS, STE_GP_INVERSE_COLS = 0, 1, 2
 STE_PREP_SPHERE = 0
 STE_PREP_WGS84 = 1
 STE_PREP_STATUS_NOCONV = 0x1

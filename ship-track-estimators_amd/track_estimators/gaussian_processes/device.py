@@ -17,7 +17,8 @@ JITTER = 1e-10  # GaussianProcessRegressor(alpha=1e-10), the value the reference
 class GpDeviceBatch:
     """B tracks (1-D inputs x_b, outputs y_b (n_b, nout)) resident on the GPU; evaluates the GP objective for all."""
 
-    def __init__(self, xs: Sequence[np.ndarray], ys: Sequence[np.ndarray], device="cuda:0", jitter: float = JITTER):
+    def __init__(self, xs: Sequence[np.ndarray], ys: Sequence[np.ndarray], device="cuda:0", jitter: float = JITTER,
+                 inverse_order: int = binding.STE_GP_INVERSE_AUTO):
         import torch
 
         self.torch = torch
@@ -63,6 +64,12 @@ class GpDeviceBatch:
         s.alpha, s.lml, s.grad, s.tr = (self.t_alpha.data_ptr(), self.t_lml.data_ptr(), self.t_grad.data_ptr(),
                                         self.t_tr.data_ptr())
         s.status = self.t_status.data_ptr()
+        # The kernel that forms L^-T is named explicitly once resolved, so that a replicated copy of this batch (whose B is
+        # a multiple of this one's and may cross the library's size threshold) sums in the same order: a track's first
+        # optimiser start and its restarts then see bit-identical objectives for identical theta.
+        if inverse_order == binding.STE_GP_INVERSE_AUTO:
+            inverse_order = binding.STE_GP_INVERSE_COLS if B >= 128 else binding.STE_GP_INVERSE_ROWS
+        self.inverse_order = s.inverse_order = int(inverse_order)
         self.struct = s
 
     def _stream(self):
@@ -76,7 +83,8 @@ class GpDeviceBatch:
     def replicated(self, copies: int) -> "GpDeviceBatch":
         """A batch holding ``copies`` consecutive copies of this one's tracks (entry c * B + b is track b): the optimiser
         restarts of a fit run as extra batch entries that share their track's data."""
-        return GpDeviceBatch(self._xs * copies, self._ys * copies, device=self.device, jitter=self._jitter)
+        return GpDeviceBatch(self._xs * copies, self._ys * copies, device=self.device, jitter=self._jitter,
+                             inverse_order=self.inverse_order)
 
     def _set_theta(self, thetas):
         th = np.ascontiguousarray(np.asarray(thetas, dtype=np.float64).reshape(self.B, 3))

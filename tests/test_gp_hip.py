@@ -278,3 +278,31 @@ def test_fit_restarts_run_as_batch_entries():
         m = gpm.GPRegression(kernel=kernel).fit(tracks[b], gpr_kwargs={"n_restarts_optimizer": 2, "random_state": 0})
         assert np.isclose(lml[b], m.log_marginal_likelihood_value_, rtol=1e-10)
         np.testing.assert_allclose(thetas[b], m.kernel_.theta, rtol=1e-8, atol=1e-8)
+
+
+def test_replicated_batch_sees_the_same_objective_bits():
+    """A fit with restarts evaluates a track's first start in the original batch and its restarts in a replicated one whose
+    size is a multiple of the original's -- possibly across the library's size threshold for the inverse kernel (row order
+    below 128 matrices, column order from there).  The two kernels sum in different orders, so the choice is inherited by
+    the replica (ste_gp_batch_f64.inverse_order): same track, same theta -> the same bits."""
+    from track_estimators._hip import binding
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    rng = np.random.default_rng(5)
+    xs = [np.sort(rng.uniform(0, 200, size=150 + 17 * b)) for b in range(3)]
+    ys = [np.stack([np.sin(x / 20) + 0.1 * rng.standard_normal(len(x)), np.cos(x / 30)], axis=1) for x in xs]
+    theta = np.log([[1.3, 25.0, 0.05], [0.7, 40.0, 0.1], [2.0, 15.0, 0.02]])
+    small = GpDeviceBatch(xs, ys)
+    assert small.inverse_order == binding.STE_GP_INVERSE_ROWS
+    big = small.replicated(50)  # 150 matrices: on its own the library would pick the column-ordered kernel
+    assert big.B == 150 and big.inverse_order == binding.STE_GP_INVERSE_ROWS
+    l0, g0, s0 = small.objective(theta)
+    l1, g1, s1 = big.objective(np.tile(theta, (50, 1)))
+    assert not s0.any() and not s1.any()
+    for c in (0, 17, 49):
+        assert np.array_equal(l1[3 * c: 3 * c + 3], l0) and np.array_equal(g1[3 * c: 3 * c + 3], g0)
+    # and the other order differs by rounding only
+    cols = GpDeviceBatch(xs, ys, inverse_order=binding.STE_GP_INVERSE_COLS)
+    l2, g2, _ = cols.objective(theta)
+    np.testing.assert_allclose(l2, l0, rtol=1e-10)
+    np.testing.assert_allclose(g2, g0, rtol=1e-7, atol=1e-8)
