@@ -274,6 +274,8 @@ def _main(stack):
     ap.add_argument("--partition", action="store_true",
                     help="round-2 pipeline: forward passes and smoothers on disjoint CU partitions (default: they share every CU)")
     ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
+    ap.add_argument("--full-cov", action="store_true",
+                    help="keep the covariance histories as full 4x4 matrices in HBM (default: packed upper triangles)")
     ap.add_argument("--no-gp", action="store_true",
                     help="skip the `extra.gp_config4` entry (BASELINE configs[4]: one batched GP objective at 1000 x 2000, "
                          "measured after the timed region at --gpus 1)")
@@ -335,7 +337,7 @@ def _main(stack):
     sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=lo)  # seed = global track index
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     hb.lanes = args.lanes
-    db = batch.DeviceBatch(hb, device=dev, tuning=args.tuning)
+    db = batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov)
     pipe = None
     if not args.no_pipeline:
         try:
@@ -345,7 +347,7 @@ def _main(stack):
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
-    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev, tuning=args.tuning)
+    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov)
                                            for _ in range(pipe.buffers_needed - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
@@ -509,12 +511,25 @@ def _main(stack):
                                    "profiles/README.md)") if traffic_fwd is not None else None,
                 "algorithmic_bytes_per_track_step": BYTES_FWD,
                 "launch_ms": fwd_ms,
+                # `achieved` above is the contract's figure: one launch's algorithmic bytes over ITS duration.  In the
+                # pipelined run several forward launches (and the smoothers of earlier steps) share every CU for that
+                # duration, so the kernel's share of the chip is 1 / launches_in_flight; what the forward launches
+                # move together is `aggregate`, what the whole path moves is `pair`.
+                "launches_in_flight": 1 if pipe is None else len(pipe.fwd_streams),
+                "aggregate": None if pipe is None else {
+                    "achieved": achieved * len(pipe.fwd_streams), "frac": achieved * len(pipe.fwd_streams) / HBM_PEAK_GBS,
+                    "unit": "GB/s", "note": "algorithmic bytes of the forward launches in flight together over one launch duration"},
+                "alone": None if "alone_ms" not in cf else {
+                    "launch_ms": cf["alone_ms"], "achieved": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9,
+                    "frac": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "the same kernel with the chip to itself (rocprofv3 counter passes serialise kernels; "
+                            + os.path.relpath(COUNTERS_CSV, ROOT) + ")"},
                 "pair": {"algorithmic_bytes_per_track_step": BYTES_FWD + BYTES_BWD,
                          "achieved": (BYTES_FWD + BYTES_BWD) * per_s / 1e9,
                          "traffic_bytes_per_track_step": traffic_all,
                          "traffic_rate": None if traffic_all is None else traffic_all * per_s / 1e9, "unit": "GB/s",
                          "note": "forward + smoother over the timed region (they overlap in pipelined mode)"},
-                "note": "path is fp64-VALU/latency bound, not HBM bound (SURVEY.md headline 6)",
+                "note": "the path is fp64-issue bound first (SURVEY.md headline 6) and HBM bound second: see fp64_valu.executed and pair.traffic_rate",
                 "fp64_valu": {
                     "executed": None if flops_exec is None else {
                         "flops_per_track_step": flops_exec, "achieved": flops_exec * per_s / 1e12,

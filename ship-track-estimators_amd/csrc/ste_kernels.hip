@@ -553,24 +553,25 @@ template <bool kGains>
 __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], double (&P)[10], double (&V)[4][4], bool warm,
                                             double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, size_t nrow, size_t B, size_t t, double* work,
-                                            bool full_row, bool& flagged, double* first_bad) {
+                                            bool full_row, bool noise_mode, bool& flagged, double* first_bad,
+                                            const TrigReg& tk, const double (&Qv)[10]) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double T[10];
     const int st = sym_sqrt_p(P, p.fan_scale, T, V, warm);
     bool ok = true;
     FanCentre g;
-    fan_centre(x, dt, sr, cr, g, ok);
+    fan_centre(x, dt, sr, cr, g, ok, tk);
     FanMoments f;
     moments_clear(f);
     {
         double lonp, latp, lonm, latm;
-        fan_pair<0>(x, T, g, lonp, latp, lonm, latm, ok);
+        fan_pair<0>(x, T, g, lonp, latp, lonm, latm, ok, tk);
         moments_add<0, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
-        fan_pair<1>(x, T, g, lonp, latp, lonm, latm, ok);
+        fan_pair<1>(x, T, g, lonp, latp, lonm, latm, ok, tk);
         moments_add<1, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
-        fan_pair<2>(x, T, g, lonp, latp, lonm, latm, ok);
+        fan_pair<2>(x, T, g, lonp, latp, lonm, latm, ok, tk);
         moments_add<2, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
-        fan_pair<3>(x, T, g, lonp, latp, lonm, latm, ok);
+        fan_pair<3>(x, T, g, lonp, latp, lonm, latm, ok, tk);
         moments_add<3, kGains>(f, T, g.c[0], g.c[1], lonp, latp, lonm, latm);
     }
     // A lane whose inputs are already non-finite fails every range test, but its outcome is NaN on either path: it must not
@@ -635,10 +636,12 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
         st_stream(&w[(kWorkD + 1) * B], p.wi * f.Dn[0][1]);
         st_stream(&w[(kWorkD + 2) * B], p.wi * f.Dn[1][0]);
         st_stream(&w[(kWorkD + 3) * B], p.wi * f.Dn[1][1]);
-        st_stream(&w[(kWorkD + 4) * B], Pn[tix(0, 2)]);
-        st_stream(&w[(kWorkD + 5) * B], Pn[tix(1, 2)]);
-        st_stream(&w[(kWorkD + 6) * B], Pn[tix(0, 3)]);
-        st_stream(&w[(kWorkD + 7) * B], Pn[tix(1, 3)]);
+        if (noise_mode) {  // otherwise the smoother takes rows 2-3 from P_b: D[2:4, 0:2] = (P_b - b b^T - Q)[0:2, 2:4]^T
+            st_stream(&w[(kWorkD + 4) * B], Pn[tix(0, 2)]);
+            st_stream(&w[(kWorkD + 5) * B], Pn[tix(1, 2)]);
+            st_stream(&w[(kWorkD + 6) * B], Pn[tix(0, 3)]);
+            st_stream(&w[(kWorkD + 7) * B], Pn[tix(1, 3)]);
+        }
         const bool bad_now = (st & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
         if (bad_now && !flagged) *first_bad = (double)nrow;
         flagged = flagged || bad_now;
@@ -656,7 +659,7 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
-        for (int c = r; c < 4; ++c) Pn[tix(r, c)] += p.Q[r * 4 + c];
+        for (int c = r; c < 4; ++c) Pn[tix(r, c)] += Qv[tix(r, c)];
     }
     if (noise) {  // the covariance is taken about the noised mean (unscented.py:203-205): + e e^T, e = mean - x^-
         STE_UNROLL
@@ -736,8 +739,9 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
 
 // One wave per SIMD, on purpose: the step loop issues a vector instruction in ~80 % of its cycles, so a second forward
 // wave on the same SIMD gains next to nothing (measured: two per SIMD run 1.55x slower each), while waves of several
-// passes that the dispatcher doubles up on some SIMDs leave others empty.  amdgpu_waves_per_eu(1, 1) makes the
-// compiler pad the allocation to 264 registers: a second forward wave no longer fits, a smoother wave (<= 248) does.
+// passes that the dispatcher doubles up on some SIMDs leave others empty.  The kernel holds 276 registers (its state,
+// plus the sin / cos coefficients and Q kept in VGPRs); amdgpu_waves_per_eu(1, 1) would pad a smaller allocation to 264
+// anyway: a second forward wave never fits on a SIMD, a smoother wave (232) does (280 + 232 = 512).
 template <bool kGains, bool kFastUpd>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
@@ -774,6 +778,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     bool flagged = false;  // sticky: a square root of this track was clamped or did not converge
     double* first_bad = (kGains && p.rts_work) ? p.rts_work + ((size_t)p.Nmax * kWorkElems) * B + t : nullptr;
     if (first_bad) *first_bad = kNeverBad;
+    TrigReg tk;  // sin / cos polynomial coefficients, in VGPRs for the whole kernel (ste_math.h)
+    trig_reg_init(tk);
+    double Qv[10];  // (keeping Q in VGPRs as well saves 20 lane reads of spilled scalars per step but costs the 20 registers
+                    // that let a smoother wave share the SIMD: 280 + 240 > 512)
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = r; c < 4; ++c) Qv[tix(r, c)] = p.m.Q[r * 4 + c];
+    }
     double V[4][4];
     if (kGains && initial_update && ns > 0) {
         // History row 0 is the PRIOR (kalman_filter.py:76-77) while the first predict starts from the state after the
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         STE_UNROLL
         for (int e = 0; e < 10; ++e) Pc[e] = P[e];
         st |= lane_predict<true>(p.m, xc, Pc, V, false, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts, 0, B, t,
-                                 p.rts_work, true, flagged, first_bad);
+                                 p.rts_work, true, noise_mode, flagged, first_bad, tk, Qv);
     }
     if (initial_update) {
         double z0[4];
@@ -827,7 +840,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             const bool warm = (k & (kColdEvery - 1)) != 0;
             st |= lane_predict<kGains>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
-                                       upd || noise_mode, flagged, first_bad);
+                                       upd || noise_mode, noise_mode, flagged, first_bad, tk, Qv);
             if (upd) st |= lane_update<kFastUpd>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_hist(p, (size_t)k + 1, B, t, x, P);
@@ -856,7 +869,7 @@ __device__ __forceinline__ int tri_index(int r, int c) { return r * 4 - (r * (r 
 __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
                                             QuadBasis& basis, double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, double* work, size_t nrow, size_t B, size_t t,
-                                            bool full_row, bool& flagged, double* first_bad) {
+                                            bool full_row, bool noise_mode, bool& flagged, double* first_bad) {
     double Tn[4], s0[4], sp[4], sm[4], m[4], xp[4];
     int st = quad_sym_sqrt(Px, p.fan_scale, cx, basis, Tn);
     quad_propagate(x, Tn, dt, sr, cr, s0, sp, sm);
@@ -904,8 +917,10 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
             for (int s = 0; s < 4; ++s) Pb[s] += fma(ex[0], bx[s], bx[0] * ex[s]);
         }
         double* w = work + (nrow * kWorkElems) * B + t;
-        STE_UNROLL
-        for (int c = 0; c < 2; ++c) w[(kWorkD + q * 2 + c) * B] = p.wi * D[c];  // row q of D, columns 0-1
+        if (q < 2 || noise_mode) {  // rows 2-3: only with recorded noise, else the smoother takes them from P_b (see kWorkD)
+            STE_UNROLL
+            for (int c = 0; c < 2; ++c) w[(kWorkD + q * 2 + c) * B] = p.wi * D[c];  // row q of D, columns 0-1
+        }
         if (full_row) {  // elsewhere the smoother rebuilds x_b and P_b from history rows k and k + 1 (see kWorkD)
             w[(kWorkXb + q) * B] = sel4(xb, q);
             STE_UNROLL
@@ -1109,7 +1124,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
         QuadBasis cold;
         cold.valid = false;
         st |= quad_predict(p.m, cx, xc, Pc, cold, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts,
-                           p.rts_work, 0, B, t, true, flagged, first_bad);
+                           p.rts_work, 0, B, t, true, noise_mode, flagged, first_bad);
     }
     if (initial_update) {
         double z0[4];
@@ -1147,7 +1162,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t,
-                               (ui >= 0 && ui_ok) || noise_mode, flagged, first_bad);
+                               (ui >= 0 && ui_ok) || noise_mode, noise_mode, flagged, first_bad);
             if (ui >= 0 && ui_ok) st |= quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_row((size_t)k + 1);
@@ -1311,12 +1326,16 @@ __device__ __forceinline__ bool work_row_full(const KParams& p, int k, int ui, b
 }
 
 struct RecurRow {
-    double D2[8], xk[4], Pk[10];  // columns 0-1 of D of step k; filtered mean and covariance (packed) of row k
+    double D2[8], xk[4], Pk[10];  // columns 0-1 of D of step k (rows 2-3 only with recorded noise); filtered row k
 };
-__device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_t B, size_t t, RecurRow& g) {
+__device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_t B, size_t t, bool d_rows23, RecurRow& g) {
     const double* w = p.rts_work + (k * kWorkElems) * B + t;
     STE_UNROLL
-    for (int e = 0; e < 8; ++e) g.D2[e] = w[(kWorkD + e) * B];
+    for (int e = 0; e < 4; ++e) g.D2[e] = w[(kWorkD + e) * B];
+    if (d_rows23) {
+        STE_UNROLL
+        for (int e = 4; e < 8; ++e) g.D2[e] = w[(kWorkD + e) * B];
+    }
     load_vec(p.fwd_mean, k, B, t, g.xk);
     load_cov_p(p.fwd_cov, (p.flags & STE_FLAG_PACKED_COV) != 0, k, B, t, g.Pk);
 }
@@ -1350,7 +1369,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     RecurRow nxt;
     int ui_n = -1;
     if (ns > 0) {
-        load_recur_row(p, (size_t)(ns - 1), B, t, nxt);
+        load_recur_row(p, (size_t)(ns - 1), B, t, always_full, nxt);
         ui_n = p.upd_idx[(size_t)(ns - 1) * B + t];
     }
     int st = 0;
@@ -1391,6 +1410,19 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
                 D[r][2] = kappa * cur.Pk[tix(r, 2)];
                 D[r][3] = kappa * cur.Pk[tix(r, 3)];
             }
+            if (!always_full) {
+                // rows 2-3 of D's first two columns are the cross moments of (speed, heading) with (lon, lat) about the
+                // predicted mean, i.e. the corresponding entries of P^- before Q was added, and P^- = P_b - b b^T with
+                // b = x_b - x_k (no recorded noise here): D[2:4, 0:2] = (P_b - b b^T - Q)[0:2, 2:4]^T
+                double bv[4];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+                STE_UNROLL
+                for (int r = 2; r < 4; ++r) {
+                    STE_UNROLL
+                    for (int c = 0; c < 2; ++c) D[r][c] = fma(-bv[c], bv[r], Pb[tix(c, r)]) - p.m.Q[c * 4 + r];
+                }
+            }
             if (__builtin_expect(__any((double)k >= first_bad), 0)) {
                 if ((double)k >= first_bad) {
                     const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
@@ -1405,7 +1437,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             // the row of the next step: in flight during the recurrence arithmetic below (and across the loop edge)
             {
                 const int kn = clampk(k - 1);
-                load_recur_row(p, (size_t)kn, B, t, nxt);
+                load_recur_row(p, (size_t)kn, B, t, always_full, nxt);
                 ui_n = p.upd_idx[(size_t)kn * B + t];
             }
             double y[4];

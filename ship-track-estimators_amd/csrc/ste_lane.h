@@ -253,7 +253,8 @@ struct FanCentre {
     double dt_r, du, da;
 };
 
-__device__ __forceinline__ void fan_centre(const double (&x)[4], double dt, double sr, double cr, FanCentre& g, bool& ok) {
+__device__ __forceinline__ void fan_centre(const double (&x)[4], double dt, double sr, double cr, FanCentre& g, bool& ok,
+                                           const TrigReg& tk) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     g.dt_r = div_earth_radius(dt);
     g.du = sr * dt;
@@ -261,7 +262,7 @@ __device__ __forceinline__ void fan_centre(const double (&x)[4], double dt, doub
     const double lat0 = x[1] * kDeg2Rad, alpha0 = x[3] * kDeg2Rad, delta0 = x[2] * g.dt_r;
     const double a0[3] = {lat0, alpha0, delta0};
     double s_0[3], c_0[3];
-    sincos_fast_n<3>(a0, s_0, c_0, ok);
+    sincos_fast_n<3, TrigReg>(a0, s_0, c_0, ok, tk);
     g.sp0 = s_0[0];
     g.cp0 = c_0[0];
     g.sa0 = s_0[1];
@@ -282,12 +283,12 @@ __device__ __forceinline__ void fan_centre(const double (&x)[4], double dt, doub
 // are the centre's +- a small increment, so sin/cos follow from one sincos per increment by angle addition.
 template <int I>
 __device__ __forceinline__ void fan_pair(const double (&x)[4], const double (&T)[10], const FanCentre& g, double& lonp,
-                                         double& latp, double& lonm, double& latm, bool& ok) {
+                                         double& latp, double& lonm, double& latm, bool& ok, const TrigReg& tk) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     const double t0 = T[tix(0, I)], t1 = T[tix(1, I)], t2 = T[tix(2, I)], t3 = T[tix(3, I)];
     const double dl[3] = {t1 * kDeg2Rad, t3 * kDeg2Rad, t2 * g.dt_r};
     double s_d[3], c_d[3];
-    sincos_delta_n<3>(dl, s_d, c_d, ok);
+    sincos_delta_n<3, TrigReg>(dl, s_d, c_d, ok, tk);
     const double p2 = g.cp0 * s_d[0], p4 = g.sp0 * s_d[0], a2 = g.ca0 * s_d[1], a4 = g.sa0 * s_d[1], d2 = g.cd0 * s_d[2],
                  d4 = g.sd0 * s_d[2];
     const double lo[2] = {(x[0] + t0) * kDeg2Rad, (x[0] - t0) * kDeg2Rad};

@@ -211,41 +211,75 @@ __device__ __forceinline__ void sincos_delta(double d, double& s, double& c) {
 // the rare failing case with the branching scalar functions above (same formulas, so lanes that were fine get the same
 // bits either way).
 // ---------------------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void sincos_kernel_n(const double (&r)[N], double (&s)[N], double (&c)[N]) {
+// Where the sin / cos kernel polynomials take their coefficients from.  As literals (TrigLit) every use needs the 64-bit
+// constant in a register pair first -- two s_mov_b32, or, once the kernel has more live scalars than SGPRs (the
+// lane-per-track forward kernel: ~33 polynomial coefficients on top of its arguments), two v_readlane_b32 from a spilled
+// copy: 83 such reads per step.  TrigReg holds the twelve coefficients of the most used polynomials in VGPRs for the
+// whole kernel instead (the lane-per-track kernel has the registers to spare: 232 used of the 264 it is padded to).
+struct TrigLit {
+    static constexpr double s1 = 1.58969099521155010221e-10, s2 = -2.50507602534068634195e-08, s3 = 2.75573137070700676789e-06,
+                            s4 = -1.98412698298579493134e-04, s5 = 8.33333333332248946124e-03, s6 = -1.66666666666666324348e-01;
+    static constexpr double c1 = -1.13596475577881948265e-11, c2 = 2.08757232129817482790e-09, c3 = -2.75573143513906633035e-07,
+                            c4 = 2.48015872894767294178e-05, c5 = -1.38888888888741095749e-03, c6 = 4.16666666666666019037e-02;
+};
+struct TrigReg {
+    double s1, s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+};
+__device__ __forceinline__ double in_vgpr(double v) {  // opaque to the optimiser: the value lives in a VGPR from here on
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ void trig_reg_init(TrigReg& k) {
+    k.s1 = in_vgpr(TrigLit::s1);
+    k.s2 = in_vgpr(TrigLit::s2);
+    k.s3 = in_vgpr(TrigLit::s3);
+    k.s4 = in_vgpr(TrigLit::s4);
+    k.s5 = in_vgpr(TrigLit::s5);
+    k.s6 = in_vgpr(TrigLit::s6);
+    k.c1 = in_vgpr(TrigLit::c1);
+    k.c2 = in_vgpr(TrigLit::c2);
+    k.c3 = in_vgpr(TrigLit::c3);
+    k.c4 = in_vgpr(TrigLit::c4);
+    k.c5 = in_vgpr(TrigLit::c5);
+    k.c6 = in_vgpr(TrigLit::c6);
+}
+
+template <int N, class K = TrigLit>
+__device__ __forceinline__ void sincos_kernel_n(const double (&r)[N], double (&s)[N], double (&c)[N], const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double z[N], ps[N], pc[N];
     STE_UNROLL
     for (int i = 0; i < N; ++i) z[i] = r[i] * r[i];
     STE_UNROLL
-    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], k.s1, k.s2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], 2.75573137070700676789e-06);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], k.s3);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], -1.98412698298579493134e-04);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], k.s4);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], 8.33333333332248946124e-03);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], k.s5);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], -1.66666666666666324348e-01);
+    for (int i = 0; i < N; ++i) ps[i] = fma(z[i], ps[i], k.s6);
     STE_UNROLL
     for (int i = 0; i < N; ++i) s[i] = fma(z[i] * r[i], ps[i], r[i]);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], k.c1, k.c2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], -2.75573143513906633035e-07);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], k.c3);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], 2.48015872894767294178e-05);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], k.c4);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], -1.38888888888741095749e-03);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], k.c5);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], 4.16666666666666019037e-02);
+    for (int i = 0; i < N; ++i) pc[i] = fma(z[i], pc[i], k.c6);
     STE_UNROLL
     for (int i = 0; i < N; ++i) c[i] = fma(z[i] * z[i], pc[i], fma(-0.5, z[i], 1.0));
 }
 
 // sincos_fast for N arguments; ok &= every |x| < 2^20
-template <int N>
-__device__ __forceinline__ void sincos_fast_n(const double (&x)[N], double (&s)[N], double (&c)[N], bool& ok) {
+template <int N, class K = TrigLit>
+__device__ __forceinline__ void sincos_fast_n(const double (&x)[N], double (&s)[N], double (&c)[N], bool& ok,
+                                              const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double n[N], r[N], sk[N], ck[N];
     STE_UNROLL
@@ -257,7 +291,7 @@ __device__ __forceinline__ void sincos_fast_n(const double (&x)[N], double (&s)[
     for (int i = 0; i < N; ++i) r[i] = fma(-n[i], 1.57079632679489655800e+00, x[i]);
     STE_UNROLL
     for (int i = 0; i < N; ++i) r[i] = fma(-n[i], 6.12323399573676603587e-17, r[i]);
-    sincos_kernel_n<N>(r, sk, ck);
+    sincos_kernel_n<N, K>(r, sk, ck, k);
     STE_UNROLL
     for (int i = 0; i < N; ++i) {
         const int q = (int)n[i];
@@ -269,12 +303,13 @@ __device__ __forceinline__ void sincos_fast_n(const double (&x)[N], double (&s)[
 }
 
 // sincos_delta for N arguments; ok &= every |d| <= pi/4
-template <int N>
-__device__ __forceinline__ void sincos_delta_n(const double (&d)[N], double (&s)[N], double (&c)[N], bool& ok) {
+template <int N, class K = TrigLit>
+__device__ __forceinline__ void sincos_delta_n(const double (&d)[N], double (&s)[N], double (&c)[N], bool& ok,
+                                               const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     STE_UNROLL
     for (int i = 0; i < N; ++i) ok = ok && (fabs(d[i]) <= 0.78539816339744828);
-    sincos_kernel_n<N>(d, s, c);
+    sincos_kernel_n<N, K>(d, s, c, k);
 }
 
 template <int N>

@@ -465,7 +465,7 @@ class SmootherPipeline:
     (``ste_stream_create_cu_range``; ordinary HIP streams share a handful of queues and their launches serialise):
 
     ``shared=True`` (default)  every stream may use every compute unit.  A lane-per-track forward wave is built to hold
-        264 registers -- one per SIMD, never two -- and a smoother wave 232, so the smoothers of earlier batches slot in
+        276 registers -- one per SIMD, never two -- and a smoother wave 232, so the smoothers of earlier batches slot in
         beside the forward waves of later ones and take the issue slots those leave (a forward wave issues ~80 % of its
         cycles; a smoother wave mostly waits for memory).  ``forward_streams`` forward passes fill the chip's SIMDs
         (seven at 10 000 tracks), ``smoother_streams`` smoothers hide each other's latency (five).
@@ -502,7 +502,7 @@ class SmootherPipeline:
         self.shared = bool(shared)
         if shared:
             # no partition: forward passes and smoothers on streams that each own a hardware queue but may use every CU.
-            # A lane-per-track forward wave holds 264 registers (one per SIMD by construction), a smoother wave 232, so
+            # A lane-per-track forward wave holds 276 registers (one per SIMD by construction), a smoother wave 232, so
             # the smoother of one batch slots in beside the forward waves of the next ones and takes the issue slots they
             # leave (its waves mostly wait for memory).
             forward_cus = ncu

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""profiles/r03_counters_per_track_step.csv and r03_pmc_counters_per_launch.csv from the rocprofv3 --pmc passes of
+profiles/tools/pmc_passes_r03.sh (usage: tools/write_r03_profiles.py gpurun_out/<pmc dir>)."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+root = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].replace("void ", "").replace("(ste::KParams)", "")
+        if not k.startswith("ste::"):
+            continue
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = (path, r["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+names = sorted({n for k in acc for n in acc[k]})
+TS = 5.0e6
+with open("profiles/r03_pmc_counters_per_launch.csv", "w") as f:
+    f.write("# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp\n")
+    f.write("# (profiles/tools/pmc_passes_r03.sh: one pass per counter group, never combined with other trace domains); round-3 kernels,\n")
+    f.write("# 10 000 tracks x 500 steps = 5.0e6 track-steps per launch; average of every counter over the launches of each kernel;\n")
+    f.write("# ms = average dispatch duration while counting (counter runs serialise kernels: these are alone-on-the-chip times)\n")
+    f.write("kernel,launches,ms," + ",".join(names) + "\n")
+    for k in sorted(acc):
+        c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+        f.write('"%s",%d,%.3f,' % (k, len(dur[k]), sum(dur[k]) / len(dur[k])) + ",".join(("%.1f" % c[n]) if n in c else "" for n in names) + "\n")
+rows = [("ukf_forward", "ste::ukf_forward_l1<true, true>"), ("urtss_backward", "ste::urtss_recur_l1"),
+        ("ukf_forward_q4", "ste::ukf_forward_q4<true, false>")]
+with open("profiles/r03_counters_per_track_step.csv", "w") as f:
+    f.write("# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp   (round 3 kernels, 10 000 tracks x 500 steps\n")
+    f.write("# = 5.0e6 track-steps per launch; one --pmc pass per counter group (profiles/tools/pmc_passes_r03.sh), averages over the launches of each kernel; raw\n")
+    f.write("# averages: profiles/r03_pmc_counters_per_launch.csv).  hbm_read = FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count, profiles/README.md),\n")
+    f.write("# hbm_write = WRITE_SIZE KiB x 1024, fp64_flops = (ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) wave-instructions x 64 lanes, all / 5.0e6.\n")
+    f.write("# ukf_forward = the lane-per-track kernel the default (pipelined) run launches; ukf_forward_q4 = the quad-per-track kernel a batch on its\n")
+    f.write("# own gets at this size (bench.py's `serial` leg); urtss_backward = the recurrence smoother (one lane per track, gain solve + recurrence).\n")
+    f.write("kernel,device_kernel,hbm_read,hbm_write,fp64_flops,valu_insts_per_wave_step,salu_insts_per_wave_step,fp64_insts_per_wave_step,waves_per_launch,alone_ms\n")
+    for short, k in rows:
+        c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+        w = c["SQ_WAVES"]
+        f64 = [c["SQ_INSTS_VALU_%s_F64" % x] for x in ("ADD", "MUL", "FMA", "TRANS")]
+        flops = (f64[0] + f64[1] + f64[3] + 2 * f64[2]) * 64 / TS
+        f.write('%s,"%s",%.2f,%.2f,%.1f,%.1f,%.1f,%.1f,%d,%.3f\n' % (
+            short, k, c["FETCH_SIZE"] * 2048 / TS, c["WRITE_SIZE"] * 1024 / TS, flops, c["SQ_INSTS_VALU"] / w / 500,
+            c["SQ_INSTS_SALU"] / w / 500, sum(f64) / w / 500, w, sum(dur[k]) / len(dur[k])))
+for src, dst in (("stats/runc/*kernel_stats.csv", "profiles/r03_pipelined_kernel_stats.csv"), ("bench_k100.json", "profiles/r03_bench_default.json"),
+                 ("bench_driver_form.json", "profiles/r03_bench_driver_form.json")):
+    m = glob.glob(os.path.join(root, src))
+    if m:
+        shutil.copy(m[0], dst)
+print(open("profiles/r03_counters_per_track_step.csv").read())
