@@ -159,3 +159,50 @@ def test_pipeline_config2_shard_size():
     got, gotP = res["means_smoothed"], res["covs_smoothed"]
     assert float(np.max(np.abs(got - sm) / np.maximum(np.abs(sm), 1e-12))) < 1e-6
     assert float(np.max(np.abs(gotP - sP) / np.max(np.abs(sP), axis=(-1, -2), keepdims=True))) < 1e-5
+
+
+def test_pipeline_with_general_matrices_and_ragged_tracks():
+    """The shared pipeline with the kernels' general routes: a dense H / R (the 4x4 update instead of the closed form; that
+    forward kernel holds more registers than fit beside a smoother wave, so the smoothers have to find SIMDs of their own)
+    and tracks of different lengths.  It must finish and leave the bits of the same batches run one after the other."""
+    import types
+
+    import torch
+
+    rng = np.random.default_rng(11)
+    H = np.array([[1.0, 0.1, 0.0, 0.0], [0.0, 1.0, 0.0, 0.05], [0.0, 0.0, 0.5, 0.0], [0.0, 0.0, 0.0, 0.0]])
+    A = rng.normal(size=(4, 4)) * 0.1
+    R = A @ A.T + np.diag([0.2, 0.2, 0.5, 30.0])
+    Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6])
+    P0 = np.eye(4)
+    hbs = []
+    for seed in (1, 2):
+        sb = synthetic.make_batch(200, nobs=40, gap_h=1.0, seed0=1000 * seed)
+        tracks, dts, x0s = [], [], []
+        for b in range(200):
+            T = int(rng.integers(12, 41))
+            tracks.append(types.SimpleNamespace(z=sb.z[b][:, :T], dts=sb.dts[b][: T - 1], sog_rate=sb.sog_rate[b][:T],
+                                                cog_rate=sb.cog_rate[b][:T]))
+            dts.append(np.repeat(sb.dts[b][: T - 1] / 2, 2))
+            x0s.append(sb.z[b][:, 0])
+        hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P0)
+        hb.lanes = 1
+        hbs.append(hb)
+    want = []
+    for hb in hbs:
+        db = batch.DeviceBatch(hb)
+        db.run()
+        torch.cuda.synchronize()
+        want.append((db.download(), db.status_host()))
+    with batch.SmootherPipeline("cuda:0", ntracks=200) as pipe:
+        dbs = [batch.DeviceBatch(hb) for hb in hbs]
+        for k in range(8):
+            pipe.submit(dbs[k % 2], final=(k == 7))
+        pipe.synchronize()
+    for hb, db, (ref, st) in zip(hbs, dbs, want):
+        got = db.download()
+        for b in range(hb.B):  # rows past a track's last step are padding (never written)
+            n1 = int(hb.nsteps[b]) + 1
+            for key in ("means", "covs", "means_smoothed", "covs_smoothed"):
+                assert np.array_equal(got[key][b, :n1], ref[key][b, :n1]), (b, key)
+        assert np.array_equal(db.status_host(), st) and not (st & 0x1).any()
