@@ -48,6 +48,10 @@ NOBS = 126
 SUBSTEPS = 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6
+# measured on MI355X this round (profiles/r03_fp64_clock_probe.log, profiles/r03_pipeline_ceilings.log): what a SIMD sustains
+# in wave64 fp64 FMAs with the whole chip busy, and the counter traffic rate of the smoother kernel with the chip to itself
+VALU_SUSTAINED_INSTS_PER_SIMD = 537e6
+HBM_MEASURED_GBS = 4900.0
 BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mean/cov written
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
 FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
@@ -462,6 +466,7 @@ def _main(stack):
         if "hbm_read" in cf and "hbm_read" in cb:
             traffic_all = cf["hbm_read"] + cf["hbm_write"] + cb["hbm_read"] + cb["hbm_write"]
         flops_exec = (cf.get("fp64_flops", 0.0) + cb.get("fp64_flops", 0.0)) or None
+        valu_insts = (cf.get("valu_insts_per_wave_step", 0.0) + cb.get("valu_insts_per_wave_step", 0.0)) or None
         out = {
             "metric": "UKF+URTSS track-steps/sec (dim=4, 500-step tracks)",
             "value": value,
@@ -528,12 +533,23 @@ def _main(stack):
                          "achieved": (BYTES_FWD + BYTES_BWD) * per_s / 1e9,
                          "traffic_bytes_per_track_step": traffic_all,
                          "traffic_rate": None if traffic_all is None else traffic_all * per_s / 1e9, "unit": "GB/s",
-                         "note": "forward + smoother over the timed region (they overlap in pipelined mode)"},
-                "note": "the path is fp64-issue bound first (SURVEY.md headline 6) and HBM bound second: see fp64_valu.executed and pair.traffic_rate",
+                         "frac": (BYTES_FWD + BYTES_BWD) * per_s / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_measured_roof": None if traffic_all is None else traffic_all * per_s / 1e9 / HBM_MEASURED_GBS,
+                         "measured_roof": HBM_MEASURED_GBS,
+                         "note": "forward + smoother over the timed region (they overlap in pipelined mode); measured_roof = "
+                                 "counter traffic of the smoother kernel alone on five streams (profiles/r03_pipeline_ceilings.log)"},
+                "note": "the path is bound by fp64 issue and by HBM together (DESIGN.md section 5): pair.frac_of_measured_roof "
+                        "and fp64_valu.executed.frac_of_sustained are the two utilisations; `frac` above is one forward "
+                        "launch of the several in flight",
                 "fp64_valu": {
                     "executed": None if flops_exec is None else {
                         "flops_per_track_step": flops_exec, "achieved": flops_exec * per_s / 1e12,
                         "frac": flops_exec * per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                        "valu_insts_per_wave_step": valu_insts,
+                        "frac_of_sustained": None if valu_insts is None else
+                        valu_insts * per_s / 64.0 / (1024 * VALU_SUSTAINED_INSTS_PER_SIMD),
+                        "sustained_note": "vector instructions issued / what 1 024 SIMDs sustain on fp64 FMA chains "
+                                          "(537 M wave-instructions/s each = 70.4 TFLOP/s, profiles/r03_fp64_clock_probe.log)",
                         "source": os.path.relpath(COUNTERS_CSV, ROOT) + " (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
                                   "lanes, FMA counted as 2 flops)"},
                     "nominal": {"flops_per_track_step": FLOPS_NOMINAL, "achieved": FLOPS_NOMINAL * per_s / 1e12,

@@ -39,7 +39,7 @@ static void run(double* out, int waves, int iters_total) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double fmas_per_wave = (double)iters * 16 * kChains;
-    const double per_simd = fmas_per_wave * waves / 1024.0;  // 256 CUs x 4 SIMDs
+    const double per_simd = fmas_per_wave * (waves < 1024 ? 1024 : waves) / 1024.0;  // 256 CUs x 4 SIMDs; fewer waves: per wave
     printf("waves %5d  chains %d  %8.3f ms  %7.1f M wave-FMA/s per SIMD  (x4 clocks = %6.0f MHz if the pipe were full)  %6.1f TFLOP/s\n",
            waves, kChains, ms, per_simd / ms * 1e-3, per_simd / ms * 1e-3 * 4, fmas_per_wave * waves * 128 / ms * 1e-9);
     (void)hipEventDestroy(e0);
@@ -50,6 +50,8 @@ int main() {
     double* out;
     (void)hipMalloc(&out, sizeof(double) * 64 * 8192);
     const int total = 1 << 17;  // x16 FMAs per wave: ~2 M wave-instructions, a few ms
+    // one wave per SIMD on a part of the chip (the dispatcher spreads them): does a wave run faster when the chip is emptier?
+    for (int waves : {157, 314, 628}) run<8>(out, waves, total);
     for (int waves : {1024, 2048, 4096}) {
         run<1>(out, waves, total);
         run<2>(out, waves, total);

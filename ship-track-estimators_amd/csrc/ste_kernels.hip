@@ -780,12 +780,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (first_bad) *first_bad = kNeverBad;
     TrigReg tk;  // sin / cos polynomial coefficients, in VGPRs for the whole kernel (ste_math.h)
     trig_reg_init(tk);
-    double Qv[10];  // (keeping Q in VGPRs as well saves 20 lane reads of spilled scalars per step but costs the 20 registers
-                    // that let a smoother wave share the SIMD: 280 + 240 > 512)
+    double Qv[10];  // Q in VGPRs too: as kernel arguments its 20 words were spilled to VGPR lanes and read back every step
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
         STE_UNROLL
-        for (int c = r; c < 4; ++c) Qv[tix(r, c)] = p.m.Q[r * 4 + c];
+        for (int c = r; c < 4; ++c) Qv[tix(r, c)] = in_vgpr(p.m.Q[r * 4 + c]);
     }
     double V[4][4];
     if (kGains && initial_update && ns > 0) {

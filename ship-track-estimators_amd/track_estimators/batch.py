@@ -465,10 +465,10 @@ class SmootherPipeline:
     (``ste_stream_create_cu_range``; ordinary HIP streams share a handful of queues and their launches serialise):
 
     ``shared=True`` (default)  every stream may use every compute unit.  A lane-per-track forward wave is built to hold
-        276 registers -- one per SIMD, never two -- and a smoother wave 232, so the smoothers of earlier batches slot in
+        264 registers -- one per SIMD, never two -- and a smoother wave 240, so the smoothers of earlier batches slot in
         beside the forward waves of later ones and take the issue slots those leave (a forward wave issues ~80 % of its
         cycles; a smoother wave mostly waits for memory).  ``forward_streams`` forward passes fill the chip's SIMDs
-        (seven at 10 000 tracks), ``smoother_streams`` smoothers hide each other's latency (five).
+        (seven at 10 000 tracks), ``smoother_streams`` smoothers hide each other's latency (six).
     ``shared=False``  round 1-2's split: forward passes on the first ``forward_cus`` compute units, smoothers on the rest.
 
     Each ``DeviceBatch`` owns its histories and work rows; a batch is not resubmitted before its previous smoother has
@@ -502,7 +502,7 @@ class SmootherPipeline:
         self.shared = bool(shared)
         if shared:
             # no partition: forward passes and smoothers on streams that each own a hardware queue but may use every CU.
-            # A lane-per-track forward wave holds 276 registers (one per SIMD by construction), a smoother wave 232, so
+            # A lane-per-track forward wave holds 264 registers (one per SIMD by construction), a smoother wave 240, so
             # the smoother of one batch slots in beside the forward waves of the next ones and takes the issue slots they
             # leave (its waves mostly wait for memory).
             forward_cus = ncu
@@ -528,9 +528,10 @@ class SmootherPipeline:
             else:
                 forward_streams = max(1, min(3, -(-slots // waves)) if quad else min(8, (2 * slots + waves) // (2 * waves)))
         if smoother_streams is None:
-            # shared: measured at 10 000 and 12 500 tracks (profiles/r03_pipeline_sweeps.txt): throughput is flat from five
-            # smoothers in flight on; fewer leave their latency exposed
-            smoother_streams = 5 if shared else 2
+            # shared: measured at 10 000 and 12 500 tracks (profiles/r03_pipeline_sweeps.txt): six smoothers in flight keep
+            # up with the forward passes (five were enough until the forward kernel lost its last lane reads: 6.96 against
+            # 7.43e9 track-steps/s at 10 000 tracks); seven or eight change nothing
+            smoother_streams = 6 if shared else 2
         if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:

@@ -87,8 +87,8 @@ def test_pipeline_full_size_matches_serial():
     err = (quad.sm_mean - ref.sm_mean).abs() / ref.sm_mean.abs().clamp_min(1e-12)
     assert float(err.max()) < 1e-7  # the two lane mappings round differently, nothing more (tolerance: 1e-6)
     pipe = batch.SmootherPipeline("cuda:0", ntracks=hb.B)
-    assert (pipe.shared, pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 256, 256, 7, 5)
-    assert pipe.buffers_needed == 13
+    assert (pipe.shared, pipe.forward_cus, pipe.smoother_cus, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 256, 256, 7, 6)
+    assert pipe.buffers_needed == 14
     dbs = [batch.DeviceBatch(hb) for _ in range(3)]  # fewer sets than streams: resubmission waits for the smoother
     for k in range(8):
         pipe.submit(dbs[k % 3], final=(k == 7))
@@ -126,7 +126,7 @@ def test_pipeline_full_size_matches_serial():
 
 def test_pipeline_config2_shard_size():
     """BASELINE.json configs[2]'s shard (100 000 tracks / 8 GPUs = 12 500 tracks x 500 steps) through the default
-    pipeline for that size (six lane-per-track forward passes and five smoothers in flight, sharing the chip): seven
+    pipeline for that size (six lane-per-track forward passes and six smoothers in flight, sharing the chip): seven
     pipelined steps leave exactly the bits of a batch run on its own, and a sample of tracks matches the oracle."""
     import torch
     from oracle import ukf_oracle as orc
@@ -140,7 +140,7 @@ def test_pipeline_config2_shard_size():
     torch.cuda.synchronize()
     hb.lanes = None
     with batch.SmootherPipeline("cuda:0", ntracks=hb.B) as pipe:
-        assert (pipe.shared, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 6, 5)
+        assert (pipe.shared, len(pipe.fwd_streams), len(pipe.bwd_streams)) == (True, 6, 6)
         dbs = [batch.DeviceBatch(hb) for _ in range(4)]
         for k in range(7):
             pipe.submit(dbs[k % len(dbs)], final=(k == 6))

@@ -3,14 +3,18 @@
 
 usage: tools/kernel_resources.py <file.hip> [filter]
 """
+import os
 import re
 import subprocess
 import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=fast-honor-pragmas",
-       "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # the flags the library is built with, per file
+
+cmd = [entry._hipcc()] + entry.HIPCC_FLAGS + entry.HIPCC_FILE_FLAGS.get(os.path.basename(src), []) + [
+    "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for ln in err.splitlines():
