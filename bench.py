@@ -438,7 +438,9 @@ def _main(stack):
     steady = None
     if pipe is not None:
         skip = len(pipe.fwd_streams) + 1
-        if args.steps >= 2 * skip + 4:
+        # completions come in bursts (forward passes run in generations of as many launches as fill the chip), so the
+        # window has to span several of them: at the driver's K = 20 there is no such window and the object is null
+        if args.steps - 1 - 2 * skip >= 3 * len(pipe.fwd_streams):
             a, b = skip, args.steps - 1 - skip
             span_ms = evs[a][3].elapsed_time(evs[b][3])
             steady = {"ms_per_step": span_ms / (b - a), "value": hb.track_steps * world * (b - a) / (span_ms * 1e-3),

@@ -8,12 +8,13 @@ H, Q, R, P0 = synthetic.example_matrices()
 B = 10000
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 kw = {}
-if len(sys.argv) > 2: kw["forward_streams"] = int(sys.argv[2])
-if len(sys.argv) > 3: kw["smoother_streams"] = int(sys.argv[3])
+quads = set(int(v) for v in sys.argv[2].split(",") if v) if len(sys.argv) > 2 else set()
+nbuf = int(sys.argv[3]) if len(sys.argv) > 3 else None
+verbose = len(sys.argv) > 4
 sb = synthetic.make_batch(B, nobs=126, gap_h=1.0, seed0=0)
 hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
 with batch.SmootherPipeline(dev, ntracks=B, **kw) as pipe:
-    dbs = [batch.DeviceBatch(hb, device=dev) for _ in range(pipe.buffers_needed)]
+    dbs = [batch.DeviceBatch(hb, device=dev) for _ in range(nbuf or pipe.buffers_needed)]
     for k in range(len(dbs)):
         pipe.submit(dbs[k]); 
     pipe.synchronize(); torch.cuda.synchronize()
@@ -24,11 +25,12 @@ with batch.SmootherPipeline(dev, ntracks=B, **kw) as pipe:
         w0 = time.perf_counter()
         t0.record(pipe.fwd_streams[0])
         for k in range(K):
-            pipe.submit(dbs[k % len(dbs)], timing=evs[k], final=(k == K - 1))
+            pipe.submit(dbs[k % len(dbs)], timing=evs[k], final=(k == K - 1), lanes=(4 if k in quads else None))
         w1 = time.perf_counter()
         pipe.synchronize(); torch.cuda.synchronize()
         w2 = time.perf_counter()
     print(f"submit {1e3*(w1-w0):.2f} ms, total {1e3*(w2-w0):.2f} ms, per step {1e3*(w2-w0)/K:.3f}")
-    for k in range(K):
+    print("quads", sorted(quads), "buffers", len(dbs))
+    for k in range(K if verbose else 0):
         a = [t0.elapsed_time(e) for e in evs[k]]
         print(f"step {k:2d} fwd {a[0]:6.2f} -> {a[1]:6.2f} ({a[1]-a[0]:.2f})  bwd {a[2]:6.2f} -> {a[3]:6.2f} ({a[3]-a[2]:.2f})")
