@@ -124,8 +124,8 @@ typedef struct ste_ukf_batch_f64 {
     int32_t* status;  /* [B] OR-ed STE_STATUS_* bits; the forward pass overwrites, the backward pass ORs */
 
     /*
-     * Optional workspace of (Nmax * STE_RTS_WORK_ROWS + 1) * B doubles (device), caller-owned.  When it is non-NULL and
-     * sog_rate_rts == cog_rate_rts == NULL, ste_ukf_forward_f64 also evaluates what the smoother's step k needs of the sigma
+     * Optional workspace of (Nmax * STE_RTS_WORK_ROWS + 1) * B doubles (device), caller-owned.  When it is non-NULL
+     * ste_ukf_forward_f64 also evaluates what the smoother's step k needs of the sigma
      * fan of the filtered state of step k (unscented.py:297-330: back-prediction x_b, P_b, cross-covariance D) while it has
      * that fan in registers, and stores it here: row k = columns 0-1 of D (8) | x_b (4) | P_b upper triangle (10) |
      * columns 2-3 of D (8), each [B].  x_b and P_b are written only for the steps where they do not follow from rows k and
@@ -134,7 +134,10 @@ typedef struct ste_ukf_batch_f64 {
      * 2 wi fan_scale times columns 2-3 of the filtered covariance); the last B words hold that step index per track.
      * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) and runs the recurrence
      * (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Results are those
-     * of the stand-alone smoother to rounding.
+     * of the stand-alone smoother to rounding.  Smoother rates of its own (sog_rate_rts / cog_rate_rts) are no obstacle:
+     * speed and heading pass through the process model as x + rate * dt, so they move x_b[2:4] -- and through it P_b,
+     * which is taken about the filtered mean -- by a known amount and leave D alone; only together with recorded noise
+     * (noise_* non-NULL) is the workspace ignored and the stand-alone smoother run.
      * NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history was not
      * produced by ste_ukf_forward_f64 on this batch).
      */

@@ -1180,8 +1180,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
 // URTSS backward pass, one lane per track (unscented.py:285-351)
 // ---------------------------------------------------------------------------------------------------------------
 // The literal smoother: recomputes the fan, its nine great-circle steps and both pseudo-inverses per step.  Used when
-// there are no work rows from the forward pass (rts_work == NULL, smoother rates that differ from the forward rates, a
-// history that ste_ukf_forward_f64 did not write, fan constants off the identities the compact rows rely on).
+// there are no work rows from the forward pass (rts_work == NULL, smoother rates of its own together with recorded noise,
+// a history that ste_ukf_forward_f64 did not write).
 __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1326,8 +1326,21 @@ __device__ __forceinline__ bool work_row_full(const KParams& p, int k, int ui, b
 
 struct RecurRow {
     double D2[8], xk[4], Pk[10];  // columns 0-1 of D of step k (rows 2-3 only with recorded noise); filtered row k
+    double shift[2];              // smoother rates that differ from the forward rates: what they add to x_b[2:4]
 };
+// Speed and heading pass through the process model as x + rate * dt (non_linear_process.py:74-75) and the position
+// components do not see the rates at all, so a smoother step that uses other rates than the forward step did
+// (unscented.py:287-292: the smoother indexes the repeated rate arrays by step) sees the same propagated fan moved by
+// (0, 0, d_sog * dt, d_cog * dt): x_b moves by that much, the fan's spread and D not at all, and P_b -- taken about the
+// filtered mean x_k (:324-325) -- becomes C + b' b'^T with the new b' = x_b' - x_k.
+template <bool kShift>
 __device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_t B, size_t t, bool d_rows23, RecurRow& g) {
+    g.shift[0] = g.shift[1] = 0.0;
+    if (kShift) {
+        const double dt = p.dt[k * B + t];
+        if (p.sog_rate_rts) g.shift[0] = (p.sog_rate_rts[k * B + t] - p.sog_rate[k * B + t]) * dt;
+        if (p.cog_rate_rts) g.shift[1] = (p.cog_rate_rts[k * B + t] - p.cog_rate[k * B + t]) * dt;
+    }
     const double* w = p.rts_work + (k * kWorkElems) * B + t;
     STE_UNROLL
     for (int e = 0; e < 4; ++e) g.D2[e] = w[(kWorkD + e) * B];
@@ -1339,6 +1352,8 @@ __device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_
     load_cov_p(p.fwd_cov, (p.flags & STE_FLAG_PACKED_COV) != 0, k, B, t, g.Pk);
 }
 
+// kShift: the smoother has rates of its own (sog_rate_rts / cog_rate_rts); compiled out for batches that share them.
+template <bool kShift>
 __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1368,7 +1383,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     RecurRow nxt;
     int ui_n = -1;
     if (ns > 0) {
-        load_recur_row(p, (size_t)(ns - 1), B, t, always_full, nxt);
+        load_recur_row<kShift>(p, (size_t)(ns - 1), B, t, always_full, nxt);
         ui_n = p.upd_idx[(size_t)(ns - 1) * B + t];
     }
     int st = 0;
@@ -1383,10 +1398,14 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             double xb[4], Pb[10];
             STE_UNROLL
             for (int c = 0; c < 4; ++c) xb[c] = xn[c];
+            if (kShift) {  // the smoother's own rates (load_recur_row)
+                xb[2] += cur.shift[0];
+                xb[3] += cur.shift[1];
+            }
             {
                 double bv[4];
                 STE_UNROLL
-                for (int c = 0; c < 4; ++c) bv[c] = xn[c] - cur.xk[c];
+                for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
                 STE_UNROLL
                 for (int r = 0; r < 4; ++r) {
                     STE_UNROLL
@@ -1399,6 +1418,23 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
                 for (int c = 0; c < 4; ++c) xb[c] = w[(kWorkXb + c) * B];
                 STE_UNROLL
                 for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
+                if (kShift) {
+                    // stored with the forward rates: P_b = C + b b^T, b = x_b - x_k; now b' = b + s, s = (0, 0, shift):
+                    // P_b' = P_b + b s^T + s b^T + s s^T (no recorded noise on this route: make_params)
+                    double bv[4];
+                    STE_UNROLL
+                    for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+                    const double s2 = cur.shift[0], s3 = cur.shift[1];
+                    Pb[tix(0, 2)] = fma(bv[0], s2, Pb[tix(0, 2)]);
+                    Pb[tix(1, 2)] = fma(bv[1], s2, Pb[tix(1, 2)]);
+                    Pb[tix(0, 3)] = fma(bv[0], s3, Pb[tix(0, 3)]);
+                    Pb[tix(1, 3)] = fma(bv[1], s3, Pb[tix(1, 3)]);
+                    Pb[tix(2, 2)] = fma(bv[2] + bv[2] + s2, s2, Pb[tix(2, 2)]);
+                    Pb[tix(3, 3)] = fma(bv[3] + bv[3] + s3, s3, Pb[tix(3, 3)]);
+                    Pb[tix(2, 3)] = fma(bv[2], s3, fma(s2, bv[3] + s3, Pb[tix(2, 3)]));
+                    xb[2] += s2;
+                    xb[3] += s3;
+                }
             }
             // the gain K = D pinv(P_b) (unscented.py:333)
             double D[4][4], K[4][4];
@@ -1436,7 +1472,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             // the row of the next step: in flight during the recurrence arithmetic below (and across the loop edge)
             {
                 const int kn = clampk(k - 1);
-                load_recur_row(p, (size_t)kn, B, t, always_full, nxt);
+                load_recur_row<kShift>(p, (size_t)kn, B, t, always_full, nxt);
                 ui_n = p.upd_idx[(size_t)kn * B + t];
             }
             double y[4];
@@ -1735,8 +1771,10 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_mean = b->sm_mean;
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
-    // the forward pass can leave the smoother's rows only when both passes use the same rates (see kWorkD)
-    kp->rts_work = (b->sog_rate_rts || b->cog_rate_rts) ? nullptr : b->rts_work;
+    // the forward pass leaves the smoother's rows (see kWorkD)
+    // (smoother rates of its own only move x_b and P_b by a known amount -- load_recur_row -- unless recorded noise sits
+    // between the weighted mean and x_b: that combination goes through the stand-alone smoother)
+    kp->rts_work = ((b->sog_rate_rts || b->cog_rate_rts) && (b->noise_pred || b->noise_upd || b->noise_rts)) ? nullptr : b->rts_work;
     return STE_OK;
 }
 
@@ -1775,7 +1813,10 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
     if (kp.rts_work) {
-        hipLaunchKernelGGL(ste::urtss_recur_l1, dim3(grid), dim3(64), 0, s, kp);
+        if (kp.sog_rate_rts || kp.cog_rate_rts)
+            hipLaunchKernelGGL(ste::urtss_recur_l1<true>, dim3(grid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL(ste::urtss_recur_l1<false>, dim3(grid), dim3(64), 0, s, kp);
         return check_hip(hipGetLastError(), "urtss_recur launch");
     }
     hipLaunchKernelGGL(ste::urtss_backward_l1, dim3(grid), dim3(64), 0, s, kp);

@@ -376,7 +376,9 @@ __device__ __forceinline__ int smoother_gain(const double (&Pb)[10], const doubl
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     const bool bad = ldl_right_solve4(Pb, D, K) || all_eig;
     int st = 0;
-    if (__builtin_expect(__any(bad), 0)) {
+    // a lane whose P_b is already non-finite (first pivot NaN: every factor and K are NaN on either route) does not send
+    // its wave through the eigenvalue route -- a dead track must not slow the live ones beside it at every step
+    if (__builtin_expect(__any(bad && Pb[0] == Pb[0]), 0)) {
         double pbm[10], dm[16], km[16];
         STE_UNROLL
         for (int e = 0; e < 10; ++e) pbm[e] = Pb[e];
@@ -404,7 +406,7 @@ __device__ __forceinline__ int quad_smoother_gain(const double (&Pb)[10], const 
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     const bool bad = ldl_right_solve_row(Pb, Drow, Krow) || all_eig;
     int st = 0;
-    if (__builtin_expect(__any(bad), 0)) {
+    if (__builtin_expect(__any(bad && Pb[0] == Pb[0]), 0)) {
         double Pbi[10];
         const int pst = sym_pinv_p(Pb, Pbi);
         if (bad) {

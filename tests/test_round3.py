@@ -99,3 +99,30 @@ def test_pipeline_first_use_of_a_buffer_set_is_no_device_barrier():
         pipe.synchronize()
         side.synchronize()
     assert side_still_running, "submit() of a fresh batch waited for unrelated work on another stream"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,nobs,s,lanes,robust", [(130, 20, 3, 1, False), (130, 20, 3, 4, False), (70, 12, 6, 0, False),
+                                                   (200, 15, 3, 4, True), (96, 30, 5, 1, False)])
+def test_work_rows_serve_a_smoother_with_rates_of_its_own(B, nobs, s, lanes, robust):
+    """The reference's smoother indexes the repeated rate arrays by step (unscented.py:287-292), which for most sub-step
+    counts is not the rate the forward step used.  Speed and heading enter the process model as x + rate * dt, so the
+    work rows of the forward pass still serve: x_b[2:4] moves by (rate_rts - rate) dt, P_b by the matching rank-two
+    term, D not at all.  Must agree with the stand-alone smoother, which propagates its own fan with its own rates."""
+    import torch
+    from track_estimators import batch
+
+    sb, hb, _ = _uniform(B, nobs, s, 500 + B)
+    assert hb.sog_rate_rts is not None or hb.cog_rate_rts is not None, "this packing shares the rates: nothing to test"
+    # make the difference count: rates that really change from observation to observation
+    assert float(np.abs(hb.sog_rate_rts - hb.sog_rate).max()) > 1e-3 or float(np.abs(hb.cog_rate_rts - hb.cog_rate).max()) > 1e-3
+    hb.lanes, hb.robust = lanes, robust
+    res = []
+    for fuse in (True, False):
+        db = batch.DeviceBatch(hb, fuse_gains=fuse)
+        assert (db.rts_work is not None) == fuse
+        db.run()
+        torch.cuda.synchronize()
+        assert not db.status_host().any()
+        res.append(db.smoothed())
+    assert mean_err(res[0][0], res[1][0]) < 1e-9 and cov_err(res[0][1], res[1][1]) < 1e-9
