@@ -136,8 +136,7 @@ typedef struct ste_ukf_batch_f64 {
      * (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Results are those
      * of the stand-alone smoother to rounding.  Smoother rates of its own (sog_rate_rts / cog_rate_rts) are no obstacle:
      * speed and heading pass through the process model as x + rate * dt, so they move x_b[2:4] -- and through it P_b,
-     * which is taken about the filtered mean -- by a known amount and leave D alone; only together with recorded noise
-     * (noise_* non-NULL) is the workspace ignored and the stand-alone smoother run.
+     * which is taken about the filtered mean -- by a known amount and leave D alone.
      * NULL = the smoother recomputes everything from fwd_mean / fwd_cov (required when the forward history was not
      * produced by ste_ukf_forward_f64 on this batch).
      */

@@ -1180,8 +1180,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
 // URTSS backward pass, one lane per track (unscented.py:285-351)
 // ---------------------------------------------------------------------------------------------------------------
 // The literal smoother: recomputes the fan, its nine great-circle steps and both pseudo-inverses per step.  Used when
-// there are no work rows from the forward pass (rts_work == NULL, smoother rates of its own together with recorded noise,
-// a history that ste_ukf_forward_f64 did not write).
+// there are no work rows from the forward pass (rts_work == NULL, a history that ste_ukf_forward_f64 did not write).
 __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     const size_t B = (size_t)p.B;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1419,11 +1418,16 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
                 STE_UNROLL
                 for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
                 if (kShift) {
-                    // stored with the forward rates: P_b = C + b b^T, b = x_b - x_k; now b' = b + s, s = (0, 0, shift):
-                    // P_b' = P_b + b s^T + s b^T + s s^T (no recorded noise on this route: make_params)
+                    // stored with the forward rates: P_b = C + b b^T with b = (weighted mean of the fan) - x_k, i.e. x_b - x_k
+                    // less the recorded noise that was added to x_b (unscented.py:319-325); now b' = b + s, s = (0, 0, shift):
+                    // P_b' = P_b + b s^T + s b^T + s s^T
                     double bv[4];
                     STE_UNROLL
                     for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+                    if (p.noise_rts) {
+                        STE_UNROLL
+                        for (int c = 0; c < 4; ++c) bv[c] -= p.noise_rts[((size_t)k * 4 + c) * B + t];
+                    }
                     const double s2 = cur.shift[0], s3 = cur.shift[1];
                     Pb[tix(0, 2)] = fma(bv[0], s2, Pb[tix(0, 2)]);
                     Pb[tix(1, 2)] = fma(bv[1], s2, Pb[tix(1, 2)]);
@@ -1772,9 +1776,8 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     kp->sm_cov = b->sm_cov;
     kp->status = b->status;
     // the forward pass leaves the smoother's rows (see kWorkD)
-    // (smoother rates of its own only move x_b and P_b by a known amount -- load_recur_row -- unless recorded noise sits
-    // between the weighted mean and x_b: that combination goes through the stand-alone smoother)
-    kp->rts_work = ((b->sog_rate_rts || b->cog_rate_rts) && (b->noise_pred || b->noise_upd || b->noise_rts)) ? nullptr : b->rts_work;
+    // (smoother rates of its own only move x_b and P_b by a known amount: load_recur_row)
+    kp->rts_work = b->rts_work;
     return STE_OK;
 }
 

@@ -356,9 +356,7 @@ class DeviceBatch:
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         # workspace for the smoother gains the forward pass can produce on the way (include/ste.h: rts_work)
         self.rts_work = None
-        own_rates = hb.sog_rate_rts is not None or hb.cog_rate_rts is not None
-        noisy = hb.noise_pred is not None or hb.noise_upd is not None or hb.noise_rts is not None
-        if alloc_smoothed and fuse_gains and N > 0 and not (own_rates and noisy):  # include/ste.h: rts_work
+        if alloc_smoothed and fuse_gains and N > 0:
             self.rts_work = torch.empty((N * binding.STE_RTS_WORK_ROWS + 1, B), **f64)  # include/ste.h: rts_work
         fan_scale, w0, wi = sigma_constants(4, hb.weights_computed)
         self._keep = (hb.H, hb.Q, hb.R)

@@ -126,3 +126,45 @@ def test_work_rows_serve_a_smoother_with_rates_of_its_own(B, nobs, s, lanes, rob
         assert not db.status_host().any()
         res.append(db.smoothed())
     assert mean_err(res[0][0], res[1][0]) < 1e-9 and cov_err(res[0][1], res[1][1]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_work_rows_with_recorded_noise_and_rates_of_its_own(lanes):
+    """The CLI's default: noise drawn like the reference draws it AND a smoother that reads other rates than the forward
+    pass.  x_b carries the recorded noise, P_b does not (unscented.py:319-325), so the b of P_b = C + b b^T is x_b - x_k
+    less that noise; the work-row smoother must land on the stand-alone smoother's result."""
+    import types
+
+    import torch
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(40, nobs=18, gap_h=1.0, seed0=4242)
+    rng = np.random.default_rng(9)
+    np.random.seed(77)
+    tracks, dts, x0s, noise = [], [], [], []
+    for b in range(sb.ntracks):
+        T = int(rng.integers(8, 19))
+        st = types.SimpleNamespace(z=sb.z[b][:, :T], dts=sb.dts[b][: T - 1], sog_rate=sb.sog_rate[b][:T],
+                                   cog_rate=sb.cog_rate[b][:T])
+        d = np.repeat(st.dts / 3, 3)
+        tracks.append(st)
+        dts.append(d)
+        x0s.append(st.z[:, 0])
+        noise.append(batch.draw_reference_noise(Q, R, d, st.dts))
+    hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P0, noise=noise)
+    assert hb.noise_rts is not None and (hb.sog_rate_rts is not None or hb.cog_rate_rts is not None)
+    hb.lanes = lanes
+    res = []
+    for fuse in (True, False):
+        db = batch.DeviceBatch(hb, fuse_gains=fuse)
+        assert (db.rts_work is not None) == fuse
+        db.run()
+        torch.cuda.synchronize()
+        assert not db.status_host().any()
+        res.append(db.download())
+    for b in range(hb.B):
+        n1 = int(hb.nsteps[b]) + 1
+        assert mean_err(res[0]["means_smoothed"][b, :n1], res[1]["means_smoothed"][b, :n1]) < 1e-9
+        assert cov_err(res[0]["covs_smoothed"][b, :n1], res[1]["covs_smoothed"][b, :n1]) < 1e-9
