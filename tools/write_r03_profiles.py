@@ -23,6 +23,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             seen.add(key)
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 names = sorted({n for k in acc for n in acc[k]})
+if not acc or not all(k in acc for _, k in [("f", "ste::ukf_forward_l1<true, true>")]):
+    sys.exit(f"no counter files of the round-3 kernels under {root}: nothing written")
 TS = 5.0e6
 with open("profiles/r03_pmc_counters_per_launch.csv", "w") as f:
     f.write("# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp\n")
@@ -33,7 +35,7 @@ with open("profiles/r03_pmc_counters_per_launch.csv", "w") as f:
     for k in sorted(acc):
         c = {n: sum(v) / len(v) for n, v in acc[k].items()}
         f.write('"%s",%d,%.3f,' % (k, len(dur[k]), sum(dur[k]) / len(dur[k])) + ",".join(("%.1f" % c[n]) if n in c else "" for n in names) + "\n")
-rows = [("ukf_forward", "ste::ukf_forward_l1<true, true>"), ("urtss_backward", "ste::urtss_recur_l1"),
+rows = [("ukf_forward", "ste::ukf_forward_l1<true, true>"), ("urtss_backward", "ste::urtss_recur_l1<false>"),
         ("ukf_forward_q4", "ste::ukf_forward_q4<true, false>")]
 with open("profiles/r03_counters_per_track_step.csv", "w") as f:
     f.write("# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp   (round 3 kernels, 10 000 tracks x 500 steps\n")
