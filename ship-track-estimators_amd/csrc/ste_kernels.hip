@@ -739,9 +739,9 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
 
 // One wave per SIMD, on purpose: the step loop issues a vector instruction in ~80 % of its cycles, so a second forward
 // wave on the same SIMD gains next to nothing (measured: two per SIMD run 1.55x slower each), while waves of several
-// passes that the dispatcher doubles up on some SIMDs leave others empty.  The kernel holds 276 registers (its state,
-// plus the sin / cos coefficients and Q kept in VGPRs); amdgpu_waves_per_eu(1, 1) would pad a smaller allocation to 264
-// anyway: a second forward wave never fits on a SIMD, a smoother wave (232) does (280 + 232 = 512).
+// passes that the dispatcher doubles up on some SIMDs leave others empty.  The kernel holds 254 registers (its state,
+// plus the sin / cos coefficients and Q kept in VGPRs) and amdgpu_waves_per_eu(1, 1) pads the allocation to 264: a second
+// forward wave never fits on a SIMD, a smoother wave (234, allocation 240) does (264 + 240 <= 512).
 template <bool kGains, bool kFastUpd>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
     const size_t B = (size_t)p.B;

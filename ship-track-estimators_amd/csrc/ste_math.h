@@ -215,7 +215,7 @@ __device__ __forceinline__ void sincos_delta(double d, double& s, double& c) {
 // constant in a register pair first -- two s_mov_b32, or, once the kernel has more live scalars than SGPRs (the
 // lane-per-track forward kernel: ~33 polynomial coefficients on top of its arguments), two v_readlane_b32 from a spilled
 // copy: 83 such reads per step.  TrigReg holds the twelve coefficients of the most used polynomials in VGPRs for the
-// whole kernel instead (the lane-per-track kernel has the registers to spare: 232 used of the 264 it is padded to).
+// whole kernel instead (the lane-per-track kernel has the registers to spare below the 264 it is padded to).
 struct TrigLit {
     static constexpr double s1 = 1.58969099521155010221e-10, s2 = -2.50507602534068634195e-08, s3 = 2.75573137070700676789e-06,
                             s4 = -1.98412698298579493134e-04, s5 = 8.33333333332248946124e-03, s6 = -1.66666666666666324348e-01;
