@@ -431,6 +431,28 @@ def _main(stack):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # The exchange on its own (not the timed region): the same all-gather with nothing beside it, so that a step time can be
+    # read as max(filter, exchange) -- at the filter's speed the 16 B per track-step every rank sends to every other rank
+    # is the larger term on xGMI.
+    gather_alone = None
+    if gathered is not None:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            gathered.launch(db.sm_mean)
+            gathered.finish()
+            torch.cuda.synchronize(dev)
+        tg = torch.tensor([(time.perf_counter() - t1) / 3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        out_bytes = int(gathered.send[0].numel() * gathered.send[0].element_size())
+        gather_alone = {"ms": float(tg.item()) * 1e3, "bytes_sent_per_rank": out_bytes,
+                        "bytes_received_per_rank": out_bytes * (world - 1),
+                        "busbw_GBps": out_bytes * (world - 1) / max(float(tg.item()), 1e-12) / 1e9,
+                        "note": "one all-gather of the smoothed lon / lat of a step ([N+1][2][tracks per rank] fp64 from every "
+                                "rank to every rank) with no kernels beside it, blocking, slowest rank; in the timed region "
+                                "it is asynchronous and double-buffered under the following steps"}
+
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     # Steady state of the pipeline: completed steps between two completion events (end of a step's smoother), leaving out
@@ -502,6 +524,7 @@ def _main(stack):
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},
             "steady_state": steady,
+            "all_gather_alone": gather_alone,
             "serial": None if serial_ms is None else {
                 "ms_per_step": serial_ms, "value": track_steps_rank / (serial_ms * 1e-3), "unit": "track-steps/s",
                 "kernels_ms": serial_kernels,
