@@ -82,8 +82,10 @@ __device__ __forceinline__ void load_mat(const double* base, size_t row, size_t 
         for (int c = 0; c < 4; ++c) M[r][c] = base[(row * 16 + r * 4 + c) * B + t];
     }
 }
-// (nontemporal stores for the histories and work rows were measured: no change, 1.013 vs 1.011 ms per pipelined step)
-__device__ __forceinline__ void st_stream(double* p, double v) { *p = v; }
+// Histories and work rows are written once and read by another kernel milliseconds later: nontemporal stores (no change at
+// round 2's 1.01 ms per step; +1.2 % now that the pipeline moves 3.7 TB/s: 7.48 -> 7.57e9 track-steps/s, same box, twice;
+// nontemporal loads on the smoother's side: nothing).
+__device__ __forceinline__ void st_stream(double* p, double v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_mat(double* base, size_t row, size_t B, size_t t, const double (&M)[4][4]) {
     STE_UNROLL
     for (int r = 0; r < 4; ++r) {
