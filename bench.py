@@ -512,7 +512,7 @@ def _main(stack):
                              + "; zero injected noise; inputs resident in HBM"),
                 "total_tracks": total, "tracks_per_gpu": bmax, "steps_per_track": steps_per_track, "observations": NOBS,
                 "substeps": SUBSTEPS,
-                "parallelism": f"track-sharded x{world}" + (", RCCL all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
+                "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
                              f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
                              + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing the {pipe.forward_cus} CUs "
