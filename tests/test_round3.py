@@ -168,3 +168,37 @@ def test_work_rows_with_recorded_noise_and_rates_of_its_own(lanes):
         n1 = int(hb.nsteps[b]) + 1
         assert mean_err(res[0]["means_smoothed"][b, :n1], res[1]["means_smoothed"][b, :n1]) < 1e-9
         assert cov_err(res[0]["covs_smoothed"][b, :n1], res[1]["covs_smoothed"][b, :n1]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_one_batch_of_a_hundred_thousand_tracks():
+    """BASELINE.json configs[2]'s whole job (100 000 tracks x 500 steps) as ONE batch on one GPU: 1.5e9 work-row doubles = 12 GB,
+    i.e. byte offsets three times past 2^32 in every kernel (indices are size_t throughout), 25 GB of HBM in all.  A sample of
+    tracks from both ends, the middle and either side of 2^16 against the oracle: filtered and smoothed, means and
+    covariances."""
+    import torch
+    from oracle import ukf_oracle as orc
+    from track_estimators import batch, synthetic
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    B = 100_000
+    sb = synthetic.make_batch(B, nobs=126, gap_h=1.0, seed0=5)
+    hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
+    db = batch.DeviceBatch(hb)
+    assert db.rts_work is not None and db.rts_work.numel() * 8 > 2**32
+    db.run()
+    torch.cuda.synchronize()
+    assert not db.status_host().any()
+    sel = np.array([0, 1, 63, 64, 4999, 50_000, 65_535, 65_536, 99_998, 99_999])
+    res = db.download(track_index=torch.from_numpy(sel).to(db.device))
+    del db
+    torch.cuda.empty_cache()
+    fires = hb.upd_idx.T[sel] >= 0
+    zidx = np.where(fires, hb.upd_idx.T[sel], 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    m, P = orc.forward_batch(hb.x0.T[sel], P0, H, Q, R, hb.dt.T[sel], fires, zidx, ridx, sb.z[sel], sb.sog_rate[sel],
+                             sb.cog_rate[sel])
+    rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (len(sel), 500))
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[sel], rr, sb.sog_rate[sel], sb.cog_rate[sel])
+    assert mean_err(res["means"], m) < MEAN_TOL and mean_err(res["means_smoothed"], sm) < MEAN_TOL
+    assert cov_err(res["covs"], P) < COV_TOL and cov_err(res["covs_smoothed"], sP) < COV_TOL
