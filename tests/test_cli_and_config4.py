@@ -291,6 +291,46 @@ def test_bench_two_rank_control_flow():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "track-steps/s"
     assert out["config"]["tracks_per_gpu"] == 256 and "all-gather" in out["config"]["parallelism"]
     assert out["value"] > 0 and out["status_flagged_tracks"] == 0
+    ag = out["all_gather_alone"]  # the step's exchange timed on its own
+    assert ag["ms"] > 0 and ag["bytes_sent_per_rank"] == 501 * 2 * 256 * 8 and ag["bytes_received_per_rank"] == ag["bytes_sent_per_rank"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_line_carries_the_contract():
+    """One small N = 1 run of bench.py: exactly one JSON line with every field the driver's contract names -- the metric
+    of BASELINE.json, whole-job value, the roofline object of the dominant kernel with its traffic, the CPU baseline of the
+    same run with core count and kind -- and the parity block of the cross-check inside tolerance."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "2", "--tracks", "640",
+           "--cpu-tracks", "64", "--cpu-pool-tracks", "0", "--no-gp"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["metric"].startswith("UKF+URTSS track-steps/sec") and out["unit"] == "track-steps/s"
+    assert (out["n_gpus"], out["steps"], out["warmup"]) == (1, 30, 2) and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f64" and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert abs(out["value"] - 640 * 500 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0 and r["launch_ms"] > 0
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["unit"] == "track-steps/s"
+    par = c["gpu_vs_oracle"]
+    assert par["tracks"] == 64
+    for name in ("means", "means_smoothed"):
+        assert par[name]["max_rel_err"] < 1e-6, name
+    for name in ("covs", "covs_smoothed"):
+        assert par[name]["max_rel_err_per_matrix"] < 1e-5, name
+    assert out["steady_state"] is None or out["steady_state"]["ms_per_step"] > 0
 
 
 @pytest.mark.gpu
