@@ -275,6 +275,8 @@ def _main(stack):
     ap.add_argument("--forward-streams", type=int, default=None)
     ap.add_argument("--smoother-streams", type=int, default=None)
     ap.add_argument("--forward-lanes", type=int, default=None, help="lane mapping of the pipelined forward passes (1, 4, 0)")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="compute units the pipeline's streams leave free (for the collective's kernels; default 0)")
     ap.add_argument("--partition", action="store_true",
                     help="round-2 pipeline: forward passes and smoothers on disjoint CU partitions (default: they share every CU)")
     ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
@@ -343,11 +345,18 @@ def _main(stack):
     hb.lanes = args.lanes
     db = batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov)
     pipe = None
+    # With a collective in the step its kernels (RCCL's, and the snapshot of the send buffer) need somewhere to run: on CUs they
+    # share with forward and smoother waves they displace those (one RCCL rank on this box, 12 500 tracks: 6.2e9 track-steps/s);
+    # with 32 of the 256 CUs -- four per XCD -- kept free of the pipeline's streams: 6.8e9 (24: 6.7, 40: 6.4, 48: 6.1).
+    reserve_cus = args.reserve_cus
+    if reserve_cus is None and dist is not None and not args.no_gather and not args.partition:
+        reserve_cus = 32
     if not args.no_pipeline:
         try:
             kw = {k: v for k, v in (("forward_cus", args.forward_cus), ("forward_streams", args.forward_streams),
                                     ("smoother_streams", args.smoother_streams),
-                                    ("forward_lanes", args.forward_lanes), ("shared", False if args.partition else None)) if v is not None}
+                                    ("forward_lanes", args.forward_lanes), ("shared", False if args.partition else None),
+                                    ("reserve_cus", reserve_cus)) if v is not None}
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
@@ -515,7 +524,8 @@ def _main(stack):
                 "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
                              f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
-                             + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing the {pipe.forward_cus} CUs "
+                             + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing {pipe.forward_cus - pipe.reserve_cus} of the {pipe.forward_cus} CUs "
+                                + (f"({pipe.reserve_cus} left to the collective's kernels) " if pipe.reserve_cus else "") +
                                 "(one forward wave per SIMD by construction, smoother waves beside them; one hardware queue per stream, "
                                 if pipe.shared else
                                 f"on {pipe.forward_cus} CUs beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, ")

@@ -486,7 +486,7 @@ class SmootherPipeline:
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
                  forward_streams: Optional[int] = None, smoother_streams: Optional[int] = None, forward_lanes: int = 1,
-                 shared: Optional[bool] = None):
+                 shared: Optional[bool] = None, reserve_cus: int = 0):
         import torch
 
         self.torch = torch
@@ -545,11 +545,16 @@ class SmootherPipeline:
         self._count = 0
         self._batches = []  # weak references to the DeviceBatches that carry one of this pipeline's events
         self.buffers_needed = forward_streams + smoother_streams + 1
+        # shared mode only: the last ``reserve_cus`` compute units (spread over the XCDs: mask bit n is CU n / 8 of XCD n % 8)
+        # stay free of this pipeline's kernels -- room that a collective's own kernels can always find (multi-GPU runs)
+        self.reserve_cus = int(reserve_cus) if shared else 0
+        if not 0 <= self.reserve_cus < ncu:
+            raise ValueError(f"reserve_cus must be in 0..{ncu - 1}, got {reserve_cus!r}")
         try:
             with torch.cuda.device(self.device):
-                for first, count, n, out in ((0, self.forward_cus, forward_streams, self.fwd_streams),
-                                             (0 if shared else self.forward_cus, self.smoother_cus, smoother_streams,
-                                              self.bwd_streams)):
+                for first, count, n, out in ((0, self.forward_cus - self.reserve_cus, forward_streams, self.fwd_streams),
+                                             (0 if shared else self.forward_cus, self.smoother_cus - self.reserve_cus,
+                                              smoother_streams, self.bwd_streams)):
                     for _ in range(n):
                         h = C.c_void_p()
                         binding.check(self.lib.ste_stream_create_cu_range(first, count, C.byref(h)),
