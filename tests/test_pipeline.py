@@ -37,6 +37,18 @@ def test_pipeline_matches_serial_runs():
         assert torch.equal(db.sm_mean, sm) and torch.equal(db.sm_cov, sc) and torch.equal(db.fwd_mean, fm)
         assert not db.status_host().any()
     pipe.close()
+    # compute units left to a collective's kernels (multi-GPU runs): fewer CUs for the same work, the same bits
+    with batch.SmootherPipeline("cuda:0", ntracks=300, reserve_cus=32) as part:
+        assert part.shared and part.reserve_cus == 32
+        for db in dbs:
+            db.sm_mean.zero_()
+        for i, k in enumerate(order):
+            part.submit(dbs[k], final=(i == len(order) - 1))
+        part.synchronize()
+    for db, (sm, sc, fm) in zip(dbs, want):
+        assert torch.equal(db.sm_mean, sm) and torch.equal(db.sm_cov, sc)
+    with pytest.raises(ValueError):
+        batch.SmootherPipeline("cuda:0", ntracks=300, reserve_cus=10_000)
 
 
 def test_pipeline_hooks_and_timing_events():
