@@ -57,6 +57,7 @@ BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read +
 FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
 # rocprofv3 PMC summary of this command for the current kernel generation (see profiles/README.md for the passes)
 COUNTERS_CSV = os.path.join(ROOT, "profiles", "r03_counters_per_track_step.csv")
+EVENT_EVERY = 4  # steps between two steps whose kernels are bracketed by HIP events (see the timed loop)
 
 
 def load_counters():
@@ -426,7 +427,11 @@ def _main(stack):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    evs = [[ev(), ev(), ev(), ev()] for _ in range(args.steps)]
+    # HIP events around the kernels of every fourth step (launch durations for the roofline object, completion marks for the
+    # steady state): each record is a packet on the stream's hardware queue between two launches, and with four of them on
+    # every step the pipeline ran 2 % slower (7.67 against 7.83e9 track-steps/s; no events at all: 7.84e9)
+    every = EVENT_EVERY
+    evs = [[ev(), ev(), ev(), ev()] if k % every == 0 else None for k in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k, evs[k], final=(k == args.steps - 1))  # the last smoother has nothing to hide behind: whole chip
@@ -462,8 +467,8 @@ def _main(stack):
                                 "rank to every rank) with no kernels beside it, blocking, slowest rank; in the timed region "
                                 "it is asynchronous and double-buffered under the following steps"}
 
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs if e is not None]))
+    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs if e is not None]))
     # Steady state of the pipeline: completed steps between two completion events (end of a step's smoother), leaving out
     # the steps during which the pipeline fills (no smoother has anything to do yet) and drains (no forward pass left).
     steady = None
@@ -471,8 +476,8 @@ def _main(stack):
         skip = len(pipe.fwd_streams) + 1
         # completions come in bursts (forward passes run in generations of as many launches as fill the chip), so the
         # window has to span several of them: at the driver's K = 20 there is no such window and the object is null
-        if args.steps - 1 - 2 * skip >= 3 * len(pipe.fwd_streams):
-            a, b = skip, args.steps - 1 - skip
+        if args.steps - 1 - 2 * skip >= 3 * len(pipe.fwd_streams) + 2 * every:
+            a, b = -(-skip // every) * every, (args.steps - 1 - skip) // every * every  # steps that carry events
             span_ms = evs[a][3].elapsed_time(evs[b][3])
             steady = {"ms_per_step": span_ms / (b - a), "value": hb.track_steps * world * (b - a) / (span_ms * 1e-3),
                       "unit": "track-steps/s", "steps": b - a,
@@ -532,7 +537,9 @@ def _main(stack):
                              + f"{len(dbs)} sets of histories in rotation)"),
                 "lanes_per_track": args.lanes, "tuning": args.tuning, "untimed_prepass_steps": prepass,
             },
-            "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms},
+            "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms,
+                           "timed_launches": len([e for e in evs if e is not None]),
+                           "note": f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region"},
             "steady_state": steady,
             "all_gather_alone": gather_alone,
             "serial": None if serial_ms is None else {
