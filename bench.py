@@ -246,6 +246,71 @@ def measure_config3(dev, reps: int = 3):
                     "duplicate timestamps and end non-finite exactly where the reference raises LinAlgError"}
 
 
+def measure_fleet(dev, ntracks: int = 100_000, chunk: int = TRACKS_CONFIG1, reps: int = 3, sample: int = 48):
+    """BASELINE.json configs[2]'s job on ONE GPU through the product's entry point: `ntracks` DISTINCT synthetic tracks x 500
+    steps, resident in HBM, through batch.run_fleet (windows of one resident fleet through the pipelined kernels; results
+    stay in the fleet's tensors) -- beside the same job as one DeviceBatch.run() (one forward launch of 1 563 waves on
+    1 024 SIMDs, then one smoother launch).  The two must leave the same bits; a sample is checked against the oracle."""
+    import torch
+    from track_estimators import batch, synthetic
+
+    from oracle import ukf_oracle as orc
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    t0 = time.perf_counter()
+    sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=50_000_000)
+    hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
+    t_host = time.perf_counter() - t0
+    hb.lanes = 1
+    db = batch.DeviceBatch(hb, device=dev)
+    torch.cuda.synchronize(dev)
+    # one launch of everything
+    db.run()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        db.run()
+    torch.cuda.synchronize(dev)
+    one_s = (time.perf_counter() - t0) / reps
+    ref = [t.clone() for t in (db.fwd_mean, db.fwd_cov, db.sm_mean, db.sm_cov)]
+    for t in (db.fwd_mean, db.fwd_cov, db.sm_mean, db.sm_cov):
+        t.zero_()
+    with batch.SmootherPipeline(dev, ntracks=chunk) as pipe:
+        batch.run_fleet(db, chunk=chunk, pipeline=pipe)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = batch.run_fleet(db, chunk=chunk, pipeline=pipe)
+        torch.cuda.synchronize(dev)
+        fleet_s = (time.perf_counter() - t0) / reps
+        desc = f"{len(pipe.fwd_streams)} forward + {len(pipe.bwd_streams)} smoother streams, {pipe.slices} time slice(s) per forward pass"
+    same = all(torch.equal(a, b) for a, b in zip(ref, (db.fwd_mean, db.fwd_cov, db.sm_mean, db.sm_cov)))
+    del ref
+    n = min(sample, ntracks)
+    fires = hb.upd_idx.T[:n] >= 0
+    zidx = np.where(fires, hb.upd_idx.T[:n], 0)
+    ridx = np.cumsum(fires, axis=1) - fires
+    rr = np.broadcast_to(batch.rts_rate_index(hb.Nmax + 1, NOBS - 1, NOBS), (n, hb.Nmax))
+    m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
+    got = db.download(("means", "covs", "means_smoothed", "covs_smoothed"), torch.arange(n, device=dev))
+    parity = compare_histories(got, {"means": m, "covs": P, "means_smoothed": sm, "covs_smoothed": sP})
+    return {"workload": f"{ntracks} distinct synthetic tracks x {hb.Nmax} steps resident in HBM (BASELINE.json configs[2]'s job on one "
+                        f"GPU) through batch.run_fleet: {len(batch.fleet_windows(ntracks, chunk))} windows of one resident fleet, {desc}; "
+                        "results stay in the fleet's tensors",
+            "seconds": fleet_s, "track_steps": hb.track_steps, "value": hb.track_steps / fleet_s, "unit": "track-steps/s",
+            "one_launch": {"seconds": one_s, "value": hb.track_steps / one_s, "unit": "track-steps/s",
+                           "note": "the same resident fleet as ONE DeviceBatch.run(): a forward launch of "
+                                   f"{-(-ntracks // 64)} lane-per-track waves on 1 024 SIMDs, then one smoother launch"},
+            "bit_identical_to_one_launch": bool(same),
+            "flagged_tracks": int((res["status"] != 0).sum()),
+            "host_synthesis_seconds": t_host,
+            "gpu_vs_oracle": {"tracks": n, "means_max_rel_err": parity["means"]["max_rel_err"],
+                              "means_smoothed_max_rel_err": parity["means_smoothed"]["max_rel_err"],
+                              "covs_max_rel_err_per_matrix": parity["covs"]["max_rel_err_per_matrix"],
+                              "covs_smoothed_max_rel_err_per_matrix": parity["covs_smoothed"]["max_rel_err_per_matrix"]}}
+
+
 def main():
     # the pipeline's CU-masked streams are destroyed before the interpreter goes down, whatever happens in between
     with contextlib.ExitStack() as stack:
@@ -283,6 +348,11 @@ def _main(stack):
     ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="ste_ukf_batch_f64.tuning")
     ap.add_argument("--full-cov", action="store_true",
                     help="keep the covariance histories as full 4x4 matrices in HBM (default: packed upper triangles)")
+    ap.add_argument("--slices", type=int, default=None,
+                    help="time slices per pipelined forward pass (default: batch.DEFAULT_SLICES)")
+    ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
+    ap.add_argument("--fleet-tracks", type=int, default=100_000)
+    ap.add_argument("--fleet-chunk", type=int, default=TRACKS_CONFIG1, help="window size of the fleet entry (tests)")
     ap.add_argument("--no-gp", action="store_true",
                     help="skip the `extra.gp_config4` entry (BASELINE configs[4]: one batched GP objective at 1000 x 2000, "
                          "measured after the timed region at --gpus 1)")
@@ -344,7 +414,9 @@ def _main(stack):
     sb = synthetic.make_batch(B, nobs=NOBS, gap_h=1.0, seed0=lo)  # seed = global track index
     hb = batch.pack_uniform(sb, SUBSTEPS, H, Q, R, P0)
     hb.lanes = args.lanes
-    db = batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov)
+    want_gather = (world > 1 or args.force_dist) and not args.no_gather
+    mk = lambda: batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov, sm_pos=want_gather)  # noqa: E731
+    db = mk()
     pipe = None
     # With a collective in the step its kernels (RCCL's, and the snapshot of the send buffer) need somewhere to run: on CUs they
     # share with forward and smoother waves they displace those (one RCCL rank on this box, 12 500 tracks: 6.2e9 track-steps/s);
@@ -357,12 +429,11 @@ def _main(stack):
             kw = {k: v for k, v in (("forward_cus", args.forward_cus), ("forward_streams", args.forward_streams),
                                     ("smoother_streams", args.smoother_streams),
                                     ("forward_lanes", args.forward_lanes), ("shared", False if args.partition else None),
-                                    ("reserve_cus", reserve_cus)) if v is not None}
+                                    ("reserve_cus", reserve_cus), ("slices", args.slices)) if v is not None}
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
-    dbs = [db] if pipe is None else [db] + [batch.DeviceBatch(hb, device=dev, tuning=args.tuning, packed_cov=not args.full_cov)
-                                           for _ in range(pipe.buffers_needed - 1)]
+    dbs = [db] if pipe is None else [db] + [mk() for _ in range(pipe.buffers_needed - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
@@ -382,14 +453,16 @@ def _main(stack):
         if events is not None:
             events[3].record(stream)
         if gathered is not None:
-            gathered.launch(d.sm_mean)
+            gathered.launch(d.sm_pos)
 
     def one_step(k, events=None, final=False):
         d = dbs[k % len(dbs)]
         if pipe is None:
             serial_step(d, events)
         else:
-            pipe.submit(d, after_smoother=(lambda _s: gathered.launch(d.sm_mean)) if gathered is not None else None,
+            # the exchange sends the smoother's own output (sm_pos): no snapshot; the event it returns keeps the next use of
+            # this buffer set behind the collective that reads it
+            pipe.submit(d, after_smoother=(lambda _s: gathered.launch_for_pipeline(d.sm_pos)) if gathered is not None else None,
                         timing=events, final=final)
 
     def drain():
@@ -454,18 +527,39 @@ def _main(stack):
         dist.barrier()
         t1 = time.perf_counter()
         for _ in range(3):
-            gathered.launch(db.sm_mean)
+            gathered.launch(db.sm_pos)
             gathered.finish()
             torch.cuda.synchronize(dev)
         tg = torch.tensor([(time.perf_counter() - t1) / 3], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        out_bytes = int(gathered.send[0].numel() * gathered.send[0].element_size())
+        out_bytes = int(np.prod(gathered.shape)) * 8
         gather_alone = {"ms": float(tg.item()) * 1e3, "bytes_sent_per_rank": out_bytes,
                         "bytes_received_per_rank": out_bytes * (world - 1),
                         "busbw_GBps": out_bytes * (world - 1) / max(float(tg.item()), 1e-12) / 1e9,
                         "note": "one all-gather of the smoothed lon / lat of a step ([N+1][2][tracks per rank] fp64 from every "
                                 "rank to every rank) with no kernels beside it, blocking, slowest rank; in the timed region "
                                 "it is asynchronous and double-buffered under the following steps"}
+
+    # The same timed loop with the exchange switched off (not the timed region): one run then reads as filter against
+    # exchange -- `value` has the gather in every step, `filter_only` does not, `all_gather_alone` is the gather by itself.
+    filter_only = None
+    if gathered is not None:
+        saved, gathered = gathered, None
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(k, None, final=(k == args.steps - 1))
+        drain()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        tf = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        gathered = saved
+        filter_only = {"ms_per_step": float(tf.item()) / args.steps * 1e3,
+                       "value": total * int(hb.Nmax) * args.steps / float(tf.item()), "unit": "track-steps/s",
+                       "note": "the timed loop again, same pipeline (same CUs reserved), without the all-gather: what the "
+                               "exchange costs is value against this"}
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs if e is not None]))
     bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs if e is not None]))
@@ -542,6 +636,7 @@ def _main(stack):
                            "note": f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region"},
             "steady_state": steady,
             "all_gather_alone": gather_alone,
+            "filter_only": filter_only,
             "serial": None if serial_ms is None else {
                 "ms_per_step": serial_ms, "value": track_steps_rank / (serial_ms * 1e-3), "unit": "track-steps/s",
                 "kernels_ms": serial_kernels,
@@ -549,40 +644,42 @@ def _main(stack):
                         "between steps): the latency figure"},
             "status_flagged_tracks": int((status != 0).sum()),
             "roofline": {
-                "bound": "hbm", "kernel": "ukf_forward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_fwd,
-                "traffic_unit": "bytes per launch",
+                # achieved = algorithmic bytes per track-step (192 forward + 320 smoother) x the
+                # track-steps per second of the timed region, per GPU, against the 8 TB/s HBM peak.  The forward and smoother
+                # kernels of different steps share the chip in pipelined mode, so the path's rate is the whole-job rate.
+                "bound": "hbm", "kernel": "ukf_forward + urtss_recur (the path; they overlap in pipelined mode)",
+                "achieved": (BYTES_FWD + BYTES_BWD) * per_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (BYTES_FWD + BYTES_BWD) * per_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": None if traffic_all is None else traffic_all * track_steps_rank,
+                "traffic_unit": "bytes per step (one forward + one smoother launch)",
                 "traffic_source": (os.path.relpath(COUNTERS_CSV, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                    "separate passes of this command; FETCH_SIZE doubled per the gfx950 calibration in "
-                                   "profiles/README.md)") if traffic_fwd is not None else None,
-                "algorithmic_bytes_per_track_step": BYTES_FWD,
-                "launch_ms": fwd_ms,
-                # `achieved` above is the contract's figure: one launch's algorithmic bytes over ITS duration.  In the
-                # pipelined run several forward launches (and the smoothers of earlier steps) share every CU for that
-                # duration, so the kernel's share of the chip is 1 / launches_in_flight; what the forward launches
-                # move together is `aggregate`, what the whole path moves is `pair`.
-                "launches_in_flight": 1 if pipe is None else len(pipe.fwd_streams),
-                "aggregate": None if pipe is None else {
-                    "achieved": achieved * len(pipe.fwd_streams), "frac": achieved * len(pipe.fwd_streams) / HBM_PEAK_GBS,
-                    "unit": "GB/s", "note": "algorithmic bytes of the forward launches in flight together over one launch duration"},
-                "alone": None if "alone_ms" not in cf else {
-                    "launch_ms": cf["alone_ms"], "achieved": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9,
-                    "frac": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "the same kernel with the chip to itself (rocprofv3 counter passes serialise kernels; "
-                            + os.path.relpath(COUNTERS_CSV, ROOT) + ")"},
-                "pair": {"algorithmic_bytes_per_track_step": BYTES_FWD + BYTES_BWD,
-                         "achieved": (BYTES_FWD + BYTES_BWD) * per_s / 1e9,
-                         "traffic_bytes_per_track_step": traffic_all,
-                         "traffic_rate": None if traffic_all is None else traffic_all * per_s / 1e9, "unit": "GB/s",
-                         "frac": (BYTES_FWD + BYTES_BWD) * per_s / 1e9 / HBM_PEAK_GBS,
-                         "frac_of_measured_roof": None if traffic_all is None else traffic_all * per_s / 1e9 / HBM_MEASURED_GBS,
-                         "measured_roof": HBM_MEASURED_GBS,
-                         "note": "forward + smoother over the timed region (they overlap in pipelined mode); measured_roof = "
-                                 "counter traffic of the smoother kernel alone on five streams (profiles/r03_pipeline_ceilings.log)"},
-                "note": "the path is bound by fp64 issue and by HBM together (DESIGN.md section 5): pair.frac_of_measured_roof "
-                        "and fp64_valu.executed.frac_of_sustained are the two utilisations; `frac` above is one forward "
-                        "launch of the several in flight",
+                                   "profiles/README.md)") if traffic_all is not None else None,
+                "algorithmic_bytes_per_track_step": BYTES_FWD + BYTES_BWD,
+                "algorithmic_bytes_per_step": (BYTES_FWD + BYTES_BWD) * track_steps_rank,
+                "traffic_bytes_per_track_step": traffic_all,
+                "traffic_rate": None if traffic_all is None else traffic_all * per_s / 1e9,
+                "frac_of_measured_roof": None if traffic_all is None else traffic_all * per_s / 1e9 / HBM_MEASURED_GBS,
+                "measured_roof": HBM_MEASURED_GBS,
+                "measured_roof_note": "counter traffic of the smoother kernel alone on five streams (profiles/r03_pipeline_ceilings.log)",
+                # one launch of the dominant kernel over ITS duration (HIP events on its stream): in the pipelined run
+                # `launches_in_flight` forward launches and the smoothers of earlier steps share every CU for that duration
+                "per_launch": {
+                    "kernel": "ukf_forward", "algorithmic_bytes_per_track_step": BYTES_FWD, "launch_ms": fwd_ms,
+                    "time_slices_per_launch": 1 if pipe is None else pipe.slices,
+                    "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "unit": "GB/s",
+                    "traffic": traffic_fwd, "traffic_unit": "bytes per launch",
+                    "launches_in_flight": 1 if pipe is None else len(pipe.fwd_streams),
+                    "aggregate": None if pipe is None else {
+                        "achieved": achieved * len(pipe.fwd_streams), "frac": achieved * len(pipe.fwd_streams) / HBM_PEAK_GBS,
+                        "unit": "GB/s", "note": "algorithmic bytes of the forward launches in flight together over one launch duration"},
+                    "alone": None if "alone_ms" not in cf else {
+                        "launch_ms": cf["alone_ms"], "achieved": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9,
+                        "frac": BYTES_FWD * track_steps_rank / (cf["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "the same kernel with the chip to itself (rocprofv3 counter passes serialise kernels; "
+                                + os.path.relpath(COUNTERS_CSV, ROOT) + ")"}},
+                "note": "the path is bound by fp64 issue and by HBM together (DESIGN.md section 5): frac_of_measured_roof "
+                        "and fp64_valu.executed.frac_of_sustained are the two utilisations",
                 "fp64_valu": {
                     "executed": None if flops_exec is None else {
                         "flops_per_track_step": flops_exec, "achieved": flops_exec * per_s / 1e12,
@@ -657,6 +754,13 @@ def _main(stack):
                 out["extra"]["config3_modern_ships_robust"] = measure_config3(dev)
             except Exception as exc:
                 out["extra"]["config3_modern_ships_robust"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and not args.no_fleet and args.cpu_tracks > 0:
+            dbs, db, pipe = [], None, None
+            torch.cuda.empty_cache()
+            try:
+                out.setdefault("extra", {})["fleet_100k"] = measure_fleet(dev, args.fleet_tracks, chunk=args.fleet_chunk)
+            except Exception as exc:
+                out.setdefault("extra", {})["fleet_100k"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -3,7 +3,8 @@
 Batch UKF + RTS smoother over every ship of a data file, on one MI355X.
 
 Counterpart of the reference's examples/example_ukf_rts_smoother_batch.py:15-90 with its per-ship Python loop replaced by
-ONE batched launch.  Same ship selection (``ids.pop(1)`` drops the 'id.tidy' pseudo id, :16-17), same matrices (:43-52),
+``batch.run_fleet``: one batched launch for a file of a hundred ships, chip-sized windows of one resident fleet through the
+pipelined kernels for a hundred thousand.  Same ship selection (``ids.pop(1)`` drops the 'id.tidy' pseudo id, :16-17), same matrices (:43-52),
 same prior ``x0 = z[:, 0]`` (:60), same 2 sub-steps (:68), same ``dt > 48 h`` skip (:70-72) and the same "error in one
 ship does not stop the others" behaviour (:73-90; here: the track's status word).  Headless: instead of the cartopy PDF
 it writes one ``.npz`` with the filtered and smoothed histories.
@@ -74,7 +75,9 @@ def run(csv, out_path=None, sphere=False, seed_base=None, verbose=True):
             np.random.seed(seed_base + i)
         noise.append(batch.draw_reference_noise(Q, R, d, st.dts))
     hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P, noise=noise)
-    out = batch.run_batch(hb, smooth=True)
+    # the reference's per-ship loop (:19-90) as windows of one resident fleet: one launch for a file of a hundred ships,
+    # chip-sized windows through the pipelined kernels for a fleet of a hundred thousand
+    out = batch.run_fleet(hb, smooth=True)
     t2 = time.perf_counter()
     for i, sid, s in zip(kept_pos, kept, out["status"]):
         if s & 0x11:  # non-finite state (the reference: LinAlgError / IndexError inside run) -> "Error in", carry on

@@ -43,7 +43,8 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 300 /* 0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma weights must sum to one */
+#define STE_VERSION 310 /* 0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in time slices (step_begin /
+                           step_end).  0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma weights sum to one */
 
 /* error codes */
 #define STE_OK 0
@@ -62,7 +63,8 @@ extern "C" {
 #define STE_FLAG_ROBUST 0x4u /* opt-in Mahalanobis robustification of every update (check_robustness, unscented.py:353-387;
                                 the reference ships with its call site commented out, :228) */
 
-#define STE_RTS_WORK_ROWS 30 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work (+ B doubles at its end) */
+#define STE_RTS_WORK_ROWS 30 /* doubles per (step, track) of ste_ukf_batch_f64.rts_work (+ one row at its end) */
+#define STE_SLICE_ALIGN 64   /* time slices of the forward pass start and end on multiples of this many steps */
 
 /* status[] bits (per track) */
 #define STE_STATUS_NAN 0x1        /* a non-finite value reached the state or covariance */
@@ -146,6 +148,33 @@ typedef struct ste_ukf_batch_f64 {
     double chi_alpha;
     int32_t robust_max_iter;
     int32_t reserved2;
+
+    /* ---- 0.3.1 ---------------------------------------------------------------------------------------------------
+     * A WINDOW of a larger resident batch ("fleet"): every per-track array above and below is addressed
+     *      a[row * track_stride + t],   0 <= t < B,
+     * i.e. the pointers name track 0 of the window inside arrays whose rows hold track_stride tracks.  0 = B (a batch of
+     * its own).  The reference's batch dimension is its per-ship loop (examples/example_ukf_rts_smoother_batch.py:19-90);
+     * windows are how a fleet of any size goes through the GPU in chip-sized pieces without copying or re-packing
+     * (track_estimators.batch.run_fleet).  nsteps and status are [B] and simply point at the window's first entry; the
+     * last row of rts_work (first bad step per track) sits after Nmax * STE_RTS_WORK_ROWS rows of track_stride. */
+    int64_t track_stride;
+
+    /* Optional output [Nmax+1][2][track_stride]: smoothed longitude / latitude, written by the smoother beside sm_mean
+     * (rows 0 .. nsteps of every track; rows past a short track's end are left alone).  This is the tensor
+     * BASELINE configs[2] exchanges between GPUs: with it the all-gather sends the smoother's own output. */
+    double* sm_pos;
+
+    /* The forward pass in time slices: ste_ukf_forward_f64 runs steps [step_begin, step_end) of every track (step_end = 0
+     * means Nmax).  Both must be multiples of STE_SLICE_ALIGN (or 0 / Nmax); a call with step_begin = 0 starts from the
+     * prior, a later one from history row step_begin, which the previous call left -- slices must therefore be issued in
+     * order (one stream, or the caller's own ordering).  Histories, work rows and status are bit-identical to those of one
+     * call over [0, Nmax): at multiples of STE_SLICE_ALIGN the warm start of the fan's eigen-solve restarts in a whole
+     * pass too, so the history row is the complete filter state and only the launch boundary moves.  With the quad
+     * mapping (STE_FLAG_LANES_4 or a small batch) slices need full covariance histories (no STE_FLAG_PACKED_COV).  The
+     * smoother is not sliced.  What this is for: a forward launch is one indivisible wave per 64 tracks for the whole
+     * pass; in slices, the waves of several batches re-balance over the chip at every boundary. */
+    int32_t step_begin;
+    int32_t step_end;
 } ste_ukf_batch_f64;
 
 int ste_version(void);
@@ -286,10 +315,11 @@ int ste_gp_predict_f64(const ste_gp_batch_f64* b, int32_t mmax, const int32_t* m
  * A track with fewer than 2 observations has no leg: all outputs 0 (the reference raises IndexError there).
  * ------------------------------------------------------------------------------------------------------------- */
 #define STE_PREP_SPHERE 0 /* haversine_formula + heading on the 6378.137 km sphere (utils.py:75-147) */
-#define STE_PREP_STATUS_NOCONV 0x1 /* WGS84 model: Vincenty's iteration did not converge on some leg of the track (nearly
-                                      antipodal points); the reference's geographiclib would still solve such a leg */
-#define STE_PREP_WGS84 1  /* geographiclib_distance + geographiclib_heading semantics (utils.py:9-72), WGS84 inverse
-                             geodesic by Vincenty's iteration */
+#define STE_PREP_STATUS_NOCONV 0x1 /* reserved: up to 0.3.0 the WGS84 model used Vincenty's iteration, which does not converge
+                                      for nearly antipodal points, and flagged such legs here; Karney's solver (0.3.1) solves
+                                      every leg and never sets it */
+#define STE_PREP_WGS84 1  /* geographiclib_distance + geographiclib_heading semantics (utils.py:9-72): WGS84 inverse
+                             geodesic by Karney's algorithm (J. Geodesy 87, 2013), what geographiclib implements */
 
 typedef struct ste_prep_batch_f64 {
     int32_t B;            /* tracks */

@@ -1,6 +1,9 @@
 // ste_kernels.hip — batched UKF forward pass and unscented RTS smoother for gfx950 (MI355X), plus the C ABI of
-// include/ste.h.  fp64 throughout; no MFMA (4x4 contractions); the whole per-track state lives in VGPRs and no kernel of
-// this file uses LDS (the quad forward kernel exchanges rows by DPP).
+// include/ste.h.  fp64 throughout; no MFMA (4x4 contractions); the whole per-track state lives in VGPRs.  No kernel of this
+// file declares LDS or synchronises through it (the quad forward kernel exchanges rows by DPP); the quad kernels with the
+// smoother's rows or the robust loop do carry 4 096 B of compiler-allocated LDS each -- hipcc promotes a small
+// dynamically indexed private array (the q-dependent row stores) to LDS instead of scratch (SQ_INSTS_LDS in
+// profiles/r03_pmc_counters_per_launch.csv).
 //
 // Kernels:
 //   ukf_forward_l1 / ukf_forward_q4      forward filter, one lane or one DPP quad per track (chosen by batch size or by
@@ -16,6 +19,7 @@
 //   backward : unscented.py:285-351 (rts_step)
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -52,8 +56,25 @@ struct KParams {
     double* sm_mean;
     double* sm_cov;
     int32_t* status;
-    double* rts_work;  // [Nmax][kWorkElems][B] smoother gains produced by the forward pass, or nullptr
+    double* rts_work;  // [Nmax][kWorkElems][ld] smoother gains produced by the forward pass, or nullptr
+    int ld;            // tracks per row of every per-track array (ste.h: track_stride; = B for a batch of its own)
+    int k0;            // forward pass, time slices: absolute index of this launch's step 0 (0 for a whole pass); every
+                       // per-step pointer above already names row k0, Nmax is the slice's length (see slice_params)
+    double* first_bad; // [ld] the last row of rts_work (first bad square root per track), or nullptr
+    double* sm_pos;    // [Nmax+1][2][ld] smoothed lon / lat beside sm_mean, or nullptr
 };
+
+// ste.h flags are 8 bits wide; this one is set by slice_params only: the launch continues a forward pass at step k0 > 0
+constexpr unsigned kFlagContinue = 0x10000u;
+
+// A kernel argument fetched where it is used (volatile: neither merged with an earlier load of the same word nor hoisted).
+// The forward kernels sit at the edge of both register files; an argument kept live across the step loop for one rare use
+// costs spills inside the loop (with the slice offset held in a scalar register: 62 instead of 12 lane reads per step).
+__device__ __forceinline__ int late_k0() {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const volatile int __attribute__((address_space(4)))*)(ka + offsetof(KParams, k0));
+}
 
 constexpr int kColdEvery = 64;  // power of two
 
@@ -645,7 +666,7 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
             st_stream(&w[(kWorkD + 7) * B], Pn[tix(1, 3)]);
         }
         const bool bad_now = (st & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
-        if (bad_now && !flagged) *first_bad = (double)nrow;
+        if (bad_now && !flagged) *first_bad = (double)((long long)nrow + late_k0());  // absolute step index
         flagged = flagged || bad_now;
         if (flagged) {  // columns 2-3 of D = 2 wi (T T)[:, 2:4]: (2 wi scale) P_k[:, 2:4] only for an exact square root
             st_stream(&w[(kWorkD23 + 0) * B], two_wi * f.TT[0][0]);
@@ -746,15 +767,22 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
 // forward wave never fits on a SIMD, a smoother wave (234, allocation 240) does (264 + 240 <= 512).
 template <bool kGains, bool kFastUpd>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
-    const size_t B = (size_t)p.B;
+    const size_t B = (size_t)p.ld;  // row pitch of every per-track array (= the batch's own width unless it is a window)
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
-    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    if (t >= (size_t)p.B) return;
+    // A later time slice of a forward pass (slice_params): x0 / P0 name history row k0 -- the state the previous launch
+    // left, bit for bit -- and every per-step pointer row k0; the slice boundary is a multiple of kColdEvery, where the
+    // eigenvector basis restarts from the identity anyway, so nothing else has to be carried.
+    const bool cont = (p.flags & kFlagContinue) != 0;
+    const int ns = (p.nsteps ? p.nsteps[t] - p.k0 : p.Nmax);
+    if (cont && ns <= 0) return;  // this track ended in an earlier slice: its rows and its status are final
 
     double x[4], P[10];
     STE_UNROLL
     for (int c = 0; c < 4; ++c) x[c] = p.x0[c * B + t];
-    {
+    if (cont && (p.flags & STE_FLAG_PACKED_COV)) {
+        load_cov_p(p.P0, true, 0, B, t, P);
+    } else {
         // the prior enters as (P0 + P0^T) / 2: the host refuses a P0 that is not symmetric (batch._as44)
         double Pf[4][4];
         if (p.flags & STE_FLAG_SHARED_P0) {
@@ -772,14 +800,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int c = r; c < 4; ++c) P[tix(r, c)] = 0.5 * (Pf[r][c] + Pf[c][r]);
         }
     }
-    store_hist(p, 0, B, t, x, P);  // slot 0 = prior (kalman_filter.py:76-77)
+    store_hist(p, 0, B, t, x, P);  // slot 0 = prior (kalman_filter.py:76-77); a later slice rewrites row k0 with its own bits
 
-    int st = 0;
+    int st = cont ? (p.status[t] & ~STE_STATUS_NAN) : 0;  // the NaN bit is taken from the final state, as in a whole pass
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
     bool flagged = false;  // sticky: a square root of this track was clamped or did not converge
-    double* first_bad = (kGains && p.rts_work) ? p.rts_work + ((size_t)p.Nmax * kWorkElems) * B + t : nullptr;
-    if (first_bad) *first_bad = kNeverBad;
+    double* first_bad = (kGains && p.rts_work) ? p.first_bad + t : nullptr;
+    if (first_bad) {
+        if (cont)
+            flagged = *first_bad != kNeverBad;
+        else
+            *first_bad = kNeverBad;
+    }
     TrigReg tk;  // sin / cos polynomial coefficients, in VGPRs for the whole kernel (ste_math.h)
     trig_reg_init(tk);
     double Qv[10];  // Q in VGPRs too: as kernel arguments its 20 words were spilled to VGPR lanes and read back every step
@@ -934,7 +967,7 @@ __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, do
         stq |= dpp_move_i<0xB1>(stq);
         stq |= dpp_move_i<0x4E>(stq);
         const bool bad_now = stq != 0;
-        if (bad_now && !flagged && q == 0) *first_bad = (double)nrow;
+        if (bad_now && !flagged && q == 0) *first_bad = (double)((long long)nrow + late_k0());  // absolute step index
         flagged = flagged || bad_now;
         if (flagged) {
             // columns 2-3 of D (row q): 2 wi (T T)[q][2:4] -- (2 wi scale) P_k[q][2:4] only for an exact square root
@@ -1078,12 +1111,14 @@ template <bool kGains, bool kRobust>
 // access.  Alone the kernel is 5 % faster than the 362-VGPR build (no AGPR traffic), and two forward passes on the same
 // compute units take 3.5 ms together instead of 2 x 2.36: a lone wave leaves half of the fp64 pipe's issue slots unused.
 __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
-    const size_t B = (size_t)p.B;
+    const size_t B = (size_t)p.ld;  // row pitch of every per-track array
     const size_t gl = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t t = gl >> 2;
     const int q = (int)(gl & 3);
-    if (t >= B) return;  // whole quads leave together
-    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    if (t >= (size_t)p.B) return;  // whole quads leave together
+    const bool cont = (p.flags & kFlagContinue) != 0;  // a later time slice (see ukf_forward_l1; full covariances only)
+    const int ns = (p.nsteps ? p.nsteps[t] - p.k0 : p.Nmax);
+    if (cont && ns <= 0) return;
     QuadCtx cx;
     quad_ctx_init(p.m, q, cx);
 
@@ -1108,10 +1143,15 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     };
     store_row(0);  // slot 0 = prior (kalman_filter.py:76-77)
 
-    int st = 0;
+    int st = cont ? (p.status[t] & ~STE_STATUS_NAN) : 0;
     bool flagged = false;
-    double* first_bad = (kGains && p.rts_work) ? p.rts_work + ((size_t)p.Nmax * kWorkElems) * B + t : nullptr;
-    if (first_bad && q == 0) *first_bad = kNeverBad;
+    double* first_bad = (kGains && p.rts_work) ? p.first_bad + t : nullptr;
+    if (first_bad) {
+        if (cont)
+            flagged = *first_bad != kNeverBad;
+        else if (q == 0)
+            *first_bad = kNeverBad;
+    }
     const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     if (kGains && initial_update && ns > 0) {
@@ -1183,10 +1223,17 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // The literal smoother: recomputes the fan, its nine great-circle steps and both pseudo-inverses per step.  Used when
 // there are no work rows from the forward pass (rts_work == NULL, a history that ste_ukf_forward_f64 did not write).
+__device__ __forceinline__ void store_pos(const KParams& p, size_t row, size_t B, size_t t, const double (&xs)[4]) {
+    if (p.sm_pos) {  // the tensor configs[2] exchanges between GPUs: smoothed lon / lat on their own (ste.h: sm_pos)
+        st_stream(&p.sm_pos[(row * 2 + 0) * B + t], xs[0]);
+        st_stream(&p.sm_pos[(row * 2 + 1) * B + t], xs[1]);
+    }
+}
+
 __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
-    const size_t B = (size_t)p.B;
+    const size_t B = (size_t)p.ld;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
+    if (t >= (size_t)p.B) return;
     const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
     const double* srp = p.sog_rate_rts ? p.sog_rate_rts : p.sog_rate;
     const double* crp = p.cog_rate_rts ? p.cog_rate_rts : p.cog_rate;
@@ -1198,6 +1245,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
     load_cov_m(p.fwd_cov, packed, (size_t)ns, B, t, Ps);
     store_vec(p.sm_mean, (size_t)ns, B, t, xs);
     store_cov_m(p.sm_cov, packed, (size_t)ns, B, t, Ps);
+    store_pos(p, (size_t)ns, B, t, xs);
 
     // filtered row of the first step to process, prefetched
     double xn[4] = {0, 0, 0, 0}, Pn[4][4] = {};
@@ -1300,6 +1348,7 @@ __global__ __launch_bounds__(64) void urtss_backward_l1(const KParams p) {
             }
             store_vec(p.sm_mean, (size_t)k, B, t, xs);
             store_cov_m(p.sm_cov, packed, (size_t)k, B, t, Ps);
+            store_pos(p, (size_t)k, B, t, xs);
         }
     }
     if (!all_finite(xs, Ps)) st |= STE_STATUS_NAN;
@@ -1356,15 +1405,15 @@ __device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_
 // kShift: the smoother has rates of its own (sog_rate_rts / cog_rate_rts); compiled out for batches that share them.
 template <bool kShift>
 __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
-    const size_t B = (size_t)p.B;
+    const size_t B = (size_t)p.ld;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= B) return;
+    if (t >= (size_t)p.B) return;
     const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
     const bool always_full = p.noise_pred || p.noise_upd || p.noise_rts;
     const bool all_eig = (p.tuning & 0x100) != 0;
     const double kappa = (p.m.wi + p.m.wi) * p.m.fan_scale;  // D[:, 2:4] = kappa P_k[:, 2:4] for an exact square root
     // first step at and after which this track's columns 2-3 of D are stored (kNeverBad: never)
-    const double first_bad = p.rts_work[((size_t)p.Nmax * kWorkElems) * B + t];
+    const double first_bad = p.first_bad[t];
     const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
     auto clampk = [&](int k) -> int { return min(max(k, 0), last_row); };
 
@@ -1375,6 +1424,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     load_cov_p(p.fwd_cov, packed, (size_t)ns, B, t, Ps);
     store_vec(p.sm_mean, (size_t)ns, B, t, xs);
     store_cov_p(p.sm_cov, packed, (size_t)ns, B, t, Ps);
+    store_pos(p, (size_t)ns, B, t, xs);
     STE_UNROLL
     for (int c = 0; c < 4; ++c) xn[c] = xs[c];
     STE_UNROLL
@@ -1453,15 +1503,20 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             }
             if (!always_full) {
                 // rows 2-3 of D's first two columns are the cross moments of (speed, heading) with (lon, lat) about the
-                // predicted mean, i.e. the corresponding entries of P^- before Q was added, and P^- = P_b - b b^T with
-                // b = x_b - x_k (no recorded noise here): D[2:4, 0:2] = (P_b - b b^T - Q)[0:2, 2:4]^T
+                // predicted mean, i.e. the corresponding entries of P^- before Q was added.  Where the step was not followed
+                // by an update P^- is row k + 1 of the filtered history itself; on a full row (x_b, P_b stored) it is
+                // P_b - b b^T with b = x_b - x_k (no recorded noise here): D[2:4, 0:2] = (P^- - Q)[0:2, 2:4]^T.  (Forming
+                // P_b = P^- + b b^T first and subtracting b b^T again on every row cost ~eps |b_c b_r| on small cross moments.)
                 double bv[4];
                 STE_UNROLL
                 for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
                 STE_UNROLL
                 for (int r = 2; r < 4; ++r) {
                     STE_UNROLL
-                    for (int c = 0; c < 2; ++c) D[r][c] = fma(-bv[c], bv[r], Pb[tix(c, r)]) - p.m.Q[c * 4 + r];
+                    for (int c = 0; c < 2; ++c) {
+                        const double pm = full ? fma(-bv[c], bv[r], Pb[tix(c, r)]) : Pn[tix(c, r)];
+                        D[r][c] = pm - p.m.Q[c * 4 + r];
+                    }
                 }
             }
             if (__builtin_expect(__any((double)k >= first_bad), 0)) {
@@ -1520,6 +1575,7 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
             }
             store_vec(p.sm_mean, (size_t)k, B, t, xs);
             store_cov_p(p.sm_cov, packed, (size_t)k, B, t, Ps);
+            store_pos(p, (size_t)k, B, t, xs);
             // row k becomes "row k + 1" of the next step
             STE_UNROLL
             for (int c = 0; c < 4; ++c) xn[c] = cur.xk[c];
@@ -1780,6 +1836,51 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     // the forward pass leaves the smoother's rows (see kWorkD)
     // (smoother rates of its own only move x_b and P_b by a known amount: load_recur_row)
     kp->rts_work = b->rts_work;
+    if (b->track_stride != 0 && (b->track_stride < b->B || b->track_stride > 0x7fffffff))
+        return fail(STE_EINVAL, "track_stride must be 0 (= B) or in [B, 2^31): a window lies inside the rows of its fleet");
+    kp->ld = b->track_stride ? (int)b->track_stride : b->B;
+    kp->k0 = 0;
+    kp->first_bad = b->rts_work ? b->rts_work + (size_t)b->Nmax * STE_RTS_WORK_ROWS * (size_t)kp->ld : nullptr;
+    kp->sm_pos = b->sm_pos;
+    return STE_OK;
+}
+
+// The forward pass in time slices (ste.h: step_begin / step_end).  A slice that starts at step k0 > 0 is the same kernel
+// started from history row k0: x0 / P0 point at that row, every per-step array at its row k0, the histories and work
+// rows likewise, the initial update is off and Nmax is the slice's length.  Slice boundaries are multiples of
+// STE_SLICE_ALIGN = kColdEvery, the steps at which the eigenvector basis of the fan's square root restarts from the
+// identity in a whole pass too -- so the history row is the complete state and the slices reproduce the whole pass bit
+// for bit.  (The quad mapping keeps both triangles of P in its lanes and a packed history holds one: slices of that
+// combination are refused.)
+static_assert(STE_SLICE_ALIGN == ste::kColdEvery, "include/ste.h: STE_SLICE_ALIGN");
+int slice_params(const ste_ukf_batch_f64* b, ste::KParams* kp) {
+    const int k0 = b->step_begin, k1 = b->step_end ? b->step_end : b->Nmax;
+    if (k0 < 0 || k1 > b->Nmax || k0 > k1 || (k0 == k1 && b->Nmax > 0))
+        return fail(STE_EINVAL, "time slice: need 0 <= step_begin < step_end <= Nmax (step_end 0 = Nmax)");
+    if (k0 % STE_SLICE_ALIGN != 0 || (k1 != b->Nmax && k1 % STE_SLICE_ALIGN != 0))
+        return fail(STE_EINVAL, "time slice: step_begin and step_end must be multiples of STE_SLICE_ALIGN (64) or the ends of the pass");
+    if (k0 == 0 && k1 == b->Nmax) return STE_OK;
+    const bool packed = (b->flags & STE_FLAG_PACKED_COV) != 0;
+    if (packed && choose_lanes(kp->B, kp->flags) == 4)
+        return fail(STE_EINVAL, "time slices with packed covariances need the lane-per-track mapping (STE_FLAG_LANES_1)");
+    const size_t ld = (size_t)kp->ld, r0 = (size_t)k0;
+    kp->Nmax = k1 - k0;
+    kp->k0 = k0;
+    if (k0 > 0) {
+        kp->flags = (kp->flags | ste::kFlagContinue | STE_FLAG_NO_INITIAL_UPDATE) & ~STE_FLAG_SHARED_P0;
+        kp->x0 = b->fwd_mean + r0 * 4 * ld;
+        kp->P0 = b->fwd_cov + r0 * (packed ? 10 : 16) * ld;
+        kp->dt += r0 * ld;
+        kp->sog_rate += r0 * ld;
+        kp->cog_rate += r0 * ld;
+        kp->upd_idx += r0 * ld;
+        if (kp->noise_pred) kp->noise_pred += r0 * 4 * ld;
+        if (kp->noise_upd) kp->noise_upd += r0 * 4 * ld;  // row k + 1 belongs to the update after step k
+        if (kp->noise_rts) kp->noise_rts += r0 * 4 * ld;
+        kp->fwd_mean += r0 * 4 * ld;
+        kp->fwd_cov += r0 * (packed ? 10 : 16) * ld;
+        if (kp->rts_work) kp->rts_work += r0 * STE_RTS_WORK_ROWS * ld;
+    }
     return STE_OK;
 }
 
@@ -1883,6 +1984,8 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream) {
     ste::KParams kp;
     int rc = make_params(b, false, false, &kp);
     if (rc) return rc;
+    rc = slice_params(b, &kp);
+    if (rc) return rc;
     return launch_forward(kp, (hipStream_t)stream);
 }
 
@@ -1897,6 +2000,8 @@ int ste_ukf_urtss_f64(const ste_ukf_batch_f64* b, void* stream) {
     ste::KParams kp;
     int rc = make_params(b, false, true, &kp);
     if (rc) return rc;
+    if (b->step_begin != 0 || (b->step_end != 0 && b->step_end != b->Nmax))
+        return fail(STE_EINVAL, "ste_ukf_urtss_f64 runs whole passes: time slices go through ste_ukf_forward_f64");
     rc = launch_forward(kp, (hipStream_t)stream);
     if (rc) return rc;
     return launch_backward(kp, (hipStream_t)stream);

@@ -22,6 +22,7 @@ STE_FLAG_LANES_4 = 0x20
 STE_FLAG_PACKED_COV = 0x40
 
 STE_RTS_WORK_ROWS = 30  # doubles per (step, track) of ste_ukf_batch_f64.rts_work
+STE_SLICE_ALIGN = 64  # time slices of the forward pass start and end on multiples of this many steps
 
 STE_STATUS_NAN = 0x1
 STE_STATUS_CLAMPED = 0x2
@@ -71,6 +72,10 @@ class SteUkfBatchF64(C.Structure):
         ("chi_alpha", C.c_double),
         ("robust_max_iter", C.c_int32),
         ("reserved2", C.c_int32),
+        ("track_stride", C.c_int64),
+        ("sm_pos", _dp),
+        ("step_begin", C.c_int32),
+        ("step_end", C.c_int32),
     ]
 
 

@@ -332,7 +332,10 @@ class DeviceBatch:
     _PACKED_INDEX = [min(r, c) * 4 - (min(r, c) * (min(r, c) - 1)) // 2 + abs(r - c) for r in range(4) for c in range(4)]
 
     def __init__(self, hb: HostBatch, device="cuda:0", alloc_smoothed: bool = True, fuse_gains: bool = True,
-                 tuning: int = 0, packed_cov: bool = True):
+                 tuning: int = 0, packed_cov: bool = True, sm_pos: bool = False, upload: bool = True):
+        """``sm_pos``: also allocate the smoother's optional [N+1][2][B] output of smoothed lon / lat (what a multi-GPU
+        run exchanges).  ``upload=False``: allocate the input tensors without filling them -- ``upload_tracks(lo, hi)``
+        then brings the host batch up window by window (``run_fleet``)."""
         import torch
 
         self.lib = binding.require_gpu()
@@ -342,8 +345,14 @@ class DeviceBatch:
         self.t = {}
         for name in self._IN:
             a = getattr(hb, name)
-            self.t[name] = None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            if a is None:
+                self.t[name] = None
+            elif upload:
+                self.t[name] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            else:
+                self.t[name] = torch.empty(a.shape, dtype=torch.from_numpy(a[..., :0]).dtype, device=self.device)
         B, N = hb.B, hb.Nmax
+        self.ntracks, self.lo, self.parent = B, 0, None
         f64 = dict(dtype=torch.float64, device=self.device)
         self.fwd_mean = torch.empty((N + 1, 4, B), **f64)
         # covariance histories as upper triangles on the device (they are symmetric by construction); download()
@@ -353,6 +362,8 @@ class DeviceBatch:
         self.fwd_cov = torch.empty((N + 1, cov_rows, B), **f64)
         self.sm_mean = torch.empty((N + 1, 4, B), **f64) if alloc_smoothed else None
         self.sm_cov = torch.empty((N + 1, cov_rows, B), **f64) if alloc_smoothed else None
+        # rows past a short track's end are never written: zeros, so that a gathered tensor is defined everywhere
+        self.sm_pos = torch.zeros((N + 1, 2, B), **f64) if (alloc_smoothed and sm_pos) else None
         self.status = torch.zeros((B,), dtype=torch.int32, device=self.device)
         # workspace for the smoother gains the forward pass can produce on the way (include/ste.h: rts_work)
         self.rts_work = None
@@ -381,6 +392,9 @@ class DeviceBatch:
         s.sm_cov = None if self.sm_cov is None else self.sm_cov.data_ptr()
         s.status = self.status.data_ptr()
         s.rts_work = None if self.rts_work is None else self.rts_work.data_ptr()
+        s.track_stride = 0
+        s.sm_pos = None if self.sm_pos is None else self.sm_pos.data_ptr()
+        s.step_begin = s.step_end = 0
         self.struct = s
         # The uploads above were queued on the current stream.  One event, recorded now, is what other streams wait on
         # before the first launch (SmootherPipeline.submit): waiting on the current stream *at submit time* would put a
@@ -389,21 +403,109 @@ class DeviceBatch:
         self._uploaded = torch.cuda.Event()
         self._uploaded.record(torch.cuda.current_stream(self.device))
         self._pipeline_done = None
+        self._last_use = None  # event after the last forward / backward / run issued outside a pipeline
+
+    # -- windows of a resident batch ----------------------------------------------------------------------------
+    _PER_TRACK_F64 = ("x0", "dt", "sog_rate", "cog_rate", "sog_rate_rts", "cog_rate_rts", "z", "noise_pred",
+                      "noise_upd", "noise_rts", "fwd_mean", "fwd_cov", "sm_mean", "sm_cov", "rts_work", "sm_pos")
+    _PER_TRACK_I32 = ("nsteps", "upd_idx", "status")
+
+    def window(self, lo: int, hi: int) -> "DeviceBatch":
+        """Tracks [lo, hi) of this resident batch as a batch of their own: same tensors, a batch struct whose pointers
+        name track ``lo`` and whose ``track_stride`` is this batch's width (include/ste.h) -- nothing is copied.  The
+        windows of a fleet go through ``SmootherPipeline`` like separate batches and write straight into the fleet's
+        histories (``run_fleet``)."""
+        if not (0 <= lo < hi <= self.ntracks):
+            raise ValueError(f"window [{lo}, {hi}) outside the batch's {self.ntracks} tracks")
+        w = object.__new__(DeviceBatch)
+        w.__dict__.update(self.__dict__)
+        w.parent = self if self.parent is None else self.parent
+        w.lo, w.ntracks = self.lo + lo, hi - lo
+        s = binding.SteUkfBatchF64.from_buffer_copy(self.struct)
+        s.B = hi - lo
+        s.track_stride = self.struct.track_stride or self.struct.B
+        for name in self._PER_TRACK_F64 + self._PER_TRACK_I32:
+            ptr = getattr(s, name)
+            if ptr:
+                setattr(s, name, ptr + lo * (4 if name in self._PER_TRACK_I32 else 8))
+        if not self.hb.shared_p0:
+            s.P0 = s.P0 + lo * 8
+        w.struct = s
+        for name in ("fwd_mean", "fwd_cov", "sm_mean", "sm_cov", "sm_pos"):
+            t = getattr(self, name)
+            setattr(w, name, None if t is None else t[..., lo:hi])
+        w.status = self.status[lo:hi]
+        w._pipeline_done = None
+        w._last_use = None
+        return w
+
+    def upload_tracks(self, lo: int, hi: int, stream=None):
+        """Bring tracks [lo, hi) of the host batch into the (``upload=False``) input tensors: page-locked staging and
+        asynchronous copies on ``stream``; returns the event that marks them resident."""
+        torch = self.torch
+        stream = stream or torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            for name in self._IN:
+                ten = self.t[name]
+                if ten is None or (name == "P0" and self.hb.shared_p0):
+                    continue
+                src = getattr(self.hb, name)[..., lo:hi]
+                stage = torch.empty(src.shape, dtype=ten.dtype, pin_memory=True)
+                stage.numpy()[...] = src
+                ten[..., lo:hi].copy_(stage, non_blocking=True)
+            if self.hb.shared_p0 and lo == 0:
+                self.t["P0"].copy_(torch.from_numpy(np.ascontiguousarray(self.hb.P0)))
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return ev
 
     def _stream(self, stream):
         if stream is None:
             stream = self.torch.cuda.current_stream(self.device)
         return C.c_void_p(stream.cuda_stream)
 
-    def forward(self, stream=None):
-        binding.check(self.lib.ste_ukf_forward_f64(C.byref(self.struct), self._stream(stream)), "ste_ukf_forward_f64")
+    def _mark_use(self, stream):
+        # kernels issued outside a pipeline: a later SmootherPipeline.submit of this batch orders itself behind them
+        if stream is None:
+            stream = self.torch.cuda.current_stream(self.device)
+        if not stream.cuda_stream:
+            return  # the legacy default stream orders itself against every blocking stream (the pipeline's included)
+        self._last_use = self.torch.cuda.Event()
+        self._last_use.record(stream)
 
-    def backward(self, stream=None):
+    @staticmethod
+    def slice_bounds(nsteps: int, slices: int):
+        """Step ranges of a forward pass cut into ``slices`` time slices: boundaries on multiples of STE_SLICE_ALIGN (64
+        steps), where the eigen-solve's warm start restarts anyway, so the slices reproduce the whole pass bit for bit."""
+        a = binding.STE_SLICE_ALIGN
+        if slices <= 1 or nsteps <= a:
+            return [(0, nsteps)]
+        step = -(-nsteps // (slices * a)) * a
+        cuts = list(range(0, nsteps, step)) + [nsteps]
+        return list(zip(cuts[:-1], cuts[1:]))
+
+    def forward(self, stream=None, slices: int = 1, mark: bool = True):
+        """The forward pass; ``slices`` > 1 issues it as that many launches over consecutive step ranges (include/ste.h:
+        step_begin / step_end), bit-identical to the single launch."""
+        s = self.struct
+        try:
+            for k0, k1 in self.slice_bounds(int(s.Nmax), int(slices)):
+                s.step_begin, s.step_end = k0, k1
+                binding.check(self.lib.ste_ukf_forward_f64(C.byref(s), self._stream(stream)), "ste_ukf_forward_f64")
+        finally:
+            s.step_begin = s.step_end = 0
+        if mark:
+            self._mark_use(stream)
+
+    def backward(self, stream=None, mark: bool = True):
         binding.check(self.lib.ste_urtss_backward_f64(C.byref(self.struct), self._stream(stream)),
                       "ste_urtss_backward_f64")
+        if mark:
+            self._mark_use(stream)
 
     def run(self, stream=None):
         binding.check(self.lib.ste_ukf_urtss_f64(C.byref(self.struct), self._stream(stream)), "ste_ukf_urtss_f64")
+        self._mark_use(stream)
 
     # -- results ------------------------------------------------------------------------------------------------
     _OUT = {"means": ("fwd_mean", 4), "covs": ("fwd_cov", 16), "means_smoothed": ("sm_mean", 4),
@@ -439,6 +541,24 @@ class DeviceBatch:
             out[name] = a.reshape(a.shape[0], a.shape[1], 4, 4) if width == 16 else a
         torch.cuda.current_stream(self.device).synchronize()
         return out
+
+    def _download_into(self, names, host, lo, hi):
+        """Asynchronous part of ``download`` for one window of a fleet: each history, track-major, into rows [lo, hi) of the
+        page-locked tensors ``host[name]`` on the current stream.  Returns the device temporaries (to be kept alive until
+        the stream has been synchronised)."""
+        torch = self.torch
+        pending = []
+        for name in names:
+            attr, width = self._OUT[name]
+            t = getattr(self, attr)
+            if width == 16 and self.packed_cov:
+                if getattr(self, "_packed_index_t", None) is None:
+                    self._packed_index_t = torch.tensor(self._PACKED_INDEX, dtype=torch.int64, device=self.device)
+                t = t.index_select(1, self._packed_index_t)
+            dev_t = t.permute(2, 0, 1).contiguous()
+            host[name][lo:hi].copy_(dev_t, non_blocking=True)
+            pending.append(dev_t)
+        return pending
 
     def filtered(self):
         """(means (B, Nmax+1, 4), covs (B, Nmax+1, 4, 4)) as NumPy arrays (rows past nsteps[b] are padding)."""
@@ -486,7 +606,7 @@ class SmootherPipeline:
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
                  forward_streams: Optional[int] = None, smoother_streams: Optional[int] = None, forward_lanes: int = 1,
-                 shared: Optional[bool] = None, reserve_cus: int = 0):
+                 shared: Optional[bool] = None, reserve_cus: int = 0, slices: Optional[int] = None):
         import torch
 
         self.torch = torch
@@ -530,8 +650,10 @@ class SmootherPipeline:
         if smoother_streams is None:
             # shared: measured at 10 000 and 12 500 tracks (profiles/r03_pipeline_sweeps.txt): six smoothers in flight keep
             # up with the forward passes (five were enough until the forward kernel lost its last lane reads: 6.96 against
-            # 7.43e9 track-steps/s at 10 000 tracks); seven or eight change nothing
-            smoother_streams = 6 if shared else 2
+            # 7.43e9 track-steps/s at 10 000 tracks); seven or eight change nothing.  A larger batch fills the chip with
+            # fewer forward passes and needs as few smoothers beside them (and each buffer set is the larger for it:
+            # 224 + 240 B per track-step, 23 GB at 100 000 x 500): never more smoother streams than forward streams, at least two.
+            smoother_streams = max(2, min(6, forward_streams)) if shared else 2
         if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
@@ -545,6 +667,12 @@ class SmootherPipeline:
         self._count = 0
         self._batches = []  # weak references to the DeviceBatches that carry one of this pipeline's events
         self.buffers_needed = forward_streams + smoother_streams + 1
+        # time slices per forward pass (DeviceBatch.forward): the waves of the passes in flight re-balance over the SIMDs at
+        # every slice boundary instead of once per pass (3.6-4.5 ms at 500 steps) -- what a short sequence of batches, or
+        # a fleet of a few windows, loses at its ends
+        self.slices = DEFAULT_SLICES if slices is None else int(slices)
+        if self.slices < 1:
+            raise ValueError("slices must be >= 1")
         # shared mode only: the last ``reserve_cus`` compute units (spread over the XCDs: mask bit n is CU n / 8 of XCD n % 8)
         # stay free of this pipeline's kernels -- room that a collective's own kernels can always find (multi-GPU runs)
         self.reserve_cus = int(reserve_cus) if shared else 0
@@ -580,11 +708,13 @@ class SmootherPipeline:
     def bwd_stream(self):
         return self.bwd_streams[0]
 
-    def submit(self, db: "DeviceBatch", after_smoother=None, timing=None, final: bool = False):
+    def submit(self, db: "DeviceBatch", after_smoother=None, timing=None, final: bool = False, smooth: bool = True):
         """Queue forward + smoother of ``db``; returns the event that marks its smoother (and ``after_smoother``) done.
 
         ``after_smoother(stream)``: optional callable run with the smoother stream current, right after the smoother
-        kernels are queued (the multi-GPU driver starts its all-gather of the smoothed positions there).
+        kernels are queued (the multi-GPU driver starts its all-gather of the smoothed positions there).  It may return
+        an event; the next use of ``db``'s buffers then waits for that event too (a collective still reading them).
+        ``smooth=False``: forward pass only.
         ``timing``: optional list of four timing-enabled events, recorded before / after the forward kernel on its
         forward stream and before / after the smoother kernels on its smoother stream.
         ``final``: nothing follows this batch, so its smoother gets an unrestricted stream (the whole chip) instead of the
@@ -605,6 +735,13 @@ class SmootherPipeline:
             # uploads queued by the constructor: an event it recorded then.  (Not wait_stream(current stream): that
             # records on the legacy default stream, which drains every blocking stream -- this pipeline's included.)
             fwd_stream.wait_event(db._uploaded)
+        for name in ("_last_use", "_reader_done"):
+            # kernels issued on this batch outside the pipeline (forward / backward / run on a stream of the caller's), or a
+            # collective started by an earlier after_smoother that may still be reading its outputs
+            e = getattr(db, name, None)
+            if e is not None:
+                fwd_stream.wait_event(e)
+                setattr(db, name, None)
         if timing is not None:
             timing[0].record(fwd_stream)
         # Lane mapping of the forward pass: with several passes sharing the partition a lane per track is the better
@@ -614,20 +751,25 @@ class SmootherPipeline:
         if self.forward_lanes and not (flags & (binding.STE_FLAG_LANES_1 | binding.STE_FLAG_LANES_4)):
             db.struct.flags = flags | (binding.STE_FLAG_LANES_1 if self.forward_lanes == 1 else binding.STE_FLAG_LANES_4)
         try:
-            db.forward(fwd_stream)
+            db.forward(fwd_stream, slices=self.slices, mark=False)
         finally:
             db.struct.flags = flags
         ready = timing[1] if timing is not None else torch.cuda.Event()
         ready.record(fwd_stream)
+        if not smooth:
+            if getattr(db, "_pipeline_done", None) is None:
+                self._batches.append(weakref.ref(db))
+            db._pipeline_done = ready
+            return ready
         bwd_stream.wait_event(ready)
         if timing is not None:
             timing[2].record(bwd_stream)
-        db.backward(bwd_stream)
+        db.backward(bwd_stream, mark=False)
         if timing is not None:
             timing[3].record(bwd_stream)
         if after_smoother is not None:
             with torch.cuda.stream(bwd_stream):
-                after_smoother(bwd_stream)
+                db._reader_done = after_smoother(bwd_stream)
         done = torch.cuda.Event()
         done.record(bwd_stream)
         if getattr(db, "_pipeline_done", None) is None:
@@ -680,6 +822,8 @@ class SmootherPipeline:
 
 _live_pipelines = weakref.WeakSet()
 _atexit_registered = False
+# time slices per pipelined forward pass when SmootherPipeline is not told (see SmootherPipeline.__init__)
+DEFAULT_SLICES = 1
 
 
 def _close_live_pipelines():
@@ -707,7 +851,7 @@ def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: 
     returns.  ``model`` is ``"wgs84"`` (the ShipTrack defaults, geographiclib_distance / _heading) or ``"sphere"``
     (haversine_formula / heading).  Returns one dict per track with ``sog, cog, sog_rate, cog_rate`` (length T_b),
     ``z`` (4, T_b) = the result of ``get_measurements(include_sog=True, include_cog=True)`` (ship_track.py:197-338) and
-    ``status`` (STE_PREP_STATUS_NOCONV = 1: Vincenty's iteration hit its cap on some leg; a RuntimeWarning names the tracks).
+    ``status`` (always 0 since 0.3.1: the WGS84 model is Karney's solver, which converges on every leg).
     """
     import torch
 
@@ -752,9 +896,8 @@ def prepare_observations(lons: Sequence, lats: Sequence, gaps: Sequence, model: 
     if sth.any():
         import warnings
 
-        warnings.warn(f"WGS84 inverse (Vincenty) did not converge on some leg of track(s) {np.flatnonzero(sth).tolist()} "
-                      "(nearly antipodal observations); their speed / course over ground are approximate", RuntimeWarning,
-                      stacklevel=2)
+        warnings.warn(f"observation preparation flagged track(s) {np.flatnonzero(sth).tolist()} (status {sth[sth != 0].tolist()})",
+                      RuntimeWarning, stacklevel=2)
     res = []
     for b in range(B):
         n = nobs[b]
@@ -788,11 +931,17 @@ def prepare_ship_tracks(ship_tracks: Sequence, device="cuda:0"):
     return ship_tracks
 
 
-def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True, outputs=None):
-    """Convenience: upload, run forward (+ smoother), download.  Returns a dict of NumPy arrays (tracks in the caller's
-    order).  ``outputs``: which histories to bring back -- any of "means", "covs", "means_smoothed", "covs_smoothed"
-    (default: all that were computed); "status" and "nsteps" always come along."""
-    db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains)
+def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: bool = True, outputs=None,
+              sm_pos: bool = False):
+    """Convenience: upload, run forward (+ smoother) as ONE launch each, download.  Returns a dict of NumPy arrays (tracks
+    in the caller's order).  ``outputs``: which histories to bring back -- any of "means", "covs", "means_smoothed",
+    "covs_smoothed" (default: all that were computed); "status" and "nsteps" always come along.  A fleet larger than a
+    chip-full of waves belongs in ``run_fleet``."""
+    return _run_batch(hb, device, smooth, fuse_gains, outputs, sm_pos)[0]
+
+
+def _run_batch(hb, device, smooth, fuse_gains, outputs, sm_pos):
+    db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, fuse_gains=fuse_gains, sm_pos=sm_pos)
     if smooth:
         if hb.sog_rate_rts is not None and np.isnan(hb.sog_rate_rts[:, (hb.host_status == 0) if hb.host_status is not None else slice(None)]).any():
             raise IndexError("smoother rate expansion too short for at least one track (unscented.py:287-292,310)")
@@ -811,4 +960,112 @@ def run_batch(hb: HostBatch, device="cuda:0", smooth: bool = True, fuse_gains: b
         status = status | hb.host_status
     nsteps = hb.nsteps.copy()
     out["status"], out["nsteps"] = (status, nsteps) if inv is None else (status[inv], nsteps[inv])
+    return out, db
+
+
+def fleet_windows(ntracks: int, chunk: int):
+    """[lo, hi) ranges that cut ``ntracks`` into ceil(ntracks / chunk) windows of nearly equal size, each a whole number of
+    64-track waves (but the last)."""
+    n = max(1, -(-ntracks // max(int(chunk), 1)))
+    w = -(-ntracks // (n * 64)) * 64
+    return [(lo, min(lo + w, ntracks)) for lo in range(0, ntracks, w)]
+
+
+def run_fleet(fleet, chunk: int = 10_000, device="cuda:0", smooth: bool = True, outputs=None, pipeline=None,
+              slices: Optional[int] = None, sm_pos: bool = False):
+    """
+    UKF + URTSS over a fleet of any size -- the batch dimension of the reference's example loop
+    (examples/example_ukf_rts_smoother_batch.py:19-90, one ship at a time) at the rate the pipelined kernels sustain.
+
+    The fleet is cut into windows of about ``chunk`` tracks (length-bucketed: ``pack_tracks`` lays tracks out longest
+    first).  Windows are not copies: a window is the fleet's own tensors seen through a batch struct with
+    ``track_stride`` = the fleet's width (include/ste.h), so every window's kernels read the fleet's inputs and write the
+    fleet's histories in place.  The windows go through a ``SmootherPipeline``: the forward passes of several windows share
+    the chip with the smoothers of the windows before them.
+
+    ``fleet``: a ``HostBatch`` -- window k + 1 is uploaded (page-locked staging, a copy stream) while window k filters,
+        and each window's histories come down as soon as its smoother has finished, overlapped with the windows behind it
+        -- or a ``DeviceBatch`` that is already resident: nothing moves, the results stay in its tensors.
+    ``outputs``: histories to bring back as NumPy arrays (any of "means", "covs", "means_smoothed", "covs_smoothed");
+        default for a HostBatch: all that were computed, for a DeviceBatch: none.  "status" and "nsteps" always come along,
+        and ``"device_batch"`` is the resident fleet.
+    ``pipeline``: a ``SmootherPipeline`` to reuse (otherwise one is built for this call and closed at its end).
+    Results are those of ``run_batch`` on the same tracks with the lane-per-track mapping, bit for bit.
+    """
+    import torch
+
+    if isinstance(fleet, DeviceBatch):
+        db, hb, resident = fleet, fleet.hb, True
+        if smooth and db.sm_mean is None:
+            raise ValueError("this DeviceBatch was built without smoothed outputs (alloc_smoothed=False)")
+        outputs = () if outputs is None else tuple(outputs)
+        if len(fleet_windows(db.ntracks, chunk)) == 1:  # one window: one launch, the mapping the library picks for its size
+            db.run() if smooth else db.forward()
+            out = db.download(outputs) if outputs else {}
+            out["status"], out["nsteps"], out["device_batch"] = db.status_host(), hb.nsteps.copy(), db
+            return out
+    else:
+        hb, resident = fleet, False
+        if len(fleet_windows(hb.B, chunk)) == 1:
+            out, db = _run_batch(hb, device, smooth, True, outputs, sm_pos)
+            out["device_batch"] = db
+            return out
+        if smooth and hb.sog_rate_rts is not None and np.isnan(
+                hb.sog_rate_rts[:, (hb.host_status == 0) if hb.host_status is not None else slice(None)]).any():
+            raise IndexError("smoother rate expansion too short for at least one track (unscented.py:287-292,310)")
+        if outputs is None:
+            outputs = ("means", "covs") + (("means_smoothed", "covs_smoothed") if smooth else ())
+        outputs = tuple(outputs)
+        db = DeviceBatch(hb, device=device, alloc_smoothed=smooth, sm_pos=sm_pos, upload=False)
+    dev = db.device
+    B = db.ntracks
+    wins = fleet_windows(B, chunk)
+    own_pipe = pipeline is None
+    pipe = pipeline or SmootherPipeline(dev, ntracks=wins[0][1] - wins[0][0], slices=slices)
+    inv = None
+    if hb.order is not None:  # back to the caller's track order
+        inv = np.empty_like(hb.order)
+        inv[hb.order] = np.arange(len(hb.order))
+    # a window's histories come down while the next windows filter -- when tracks stay in place; a length-bucketed fleet
+    # is reordered on the device in one pass at the end (DeviceBatch.download)
+    stream_down = bool(outputs) and inv is None and len(wins) > 1
+    host = {}
+    try:
+        up = torch.cuda.Stream(dev) if not resident else None
+        down = torch.cuda.Stream(dev) if stream_down else None
+        if stream_down:
+            for name in outputs:
+                attr, width = DeviceBatch._OUT[name]
+                host[name] = torch.empty((B, hb.Nmax + 1, width), dtype=torch.float64, pin_memory=True)
+        keep = []
+        for i, (lo, hi) in enumerate(wins):
+            win = db.window(lo, hi) if len(wins) > 1 else db
+            if not resident:
+                win._uploaded = db.upload_tracks(lo, hi, up)
+            done = pipe.submit(win, final=(i == len(wins) - 1), smooth=smooth)
+            if stream_down:
+                down.wait_event(done)
+                with torch.cuda.stream(down):
+                    keep.append(win._download_into(outputs, host, lo, hi))
+            keep.append(win)
+        pipe.synchronize()
+        if down is not None:
+            down.synchronize()
+        db._pipeline_done = None
+    finally:
+        if own_pipe:
+            pipe.close()
+    out = {}
+    if stream_down:
+        for name in outputs:
+            a = host[name].numpy()
+            out[name] = a.reshape(a.shape[0], a.shape[1], 4, 4) if DeviceBatch._OUT[name][1] == 16 else a
+    elif outputs:
+        out = db.download(outputs, None if inv is None else torch.from_numpy(inv).to(dev))
+    status = db.status.cpu().numpy()
+    if hb.host_status is not None:
+        status = status | hb.host_status
+    nsteps = hb.nsteps.copy()
+    out["status"], out["nsteps"] = (status, nsteps) if inv is None else (status[inv], nsteps[inv])
+    out["device_batch"] = db
     return out

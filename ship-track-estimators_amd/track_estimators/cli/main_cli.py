@@ -172,7 +172,8 @@ def track_estimator(argv=None):
             noise = [batch.draw_reference_noise(np.asarray(Q), np.asarray(R), d, st.dts) for d, st in zip(dts, tracks)]
         hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, np.asarray(P, dtype=np.float64), noise=noise)
         hb.robust, hb.chi_alpha = robust, chi_alpha
-        out = batch.run_batch(hb, smooth=args.apply_rts_smoother)
+        # one launch for a few ships, windows through the pipelined kernels for a fleet (batch.run_fleet)
+        out = batch.run_fleet(hb, smooth=args.apply_rts_smoother)
         logger.info(f"Writing outputs with prefix '{args.output_prefix}'.")
         for b, sid in enumerate(ship_ids):
             if out["status"][b] & 0x1:

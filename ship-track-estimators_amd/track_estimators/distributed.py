@@ -61,43 +61,82 @@ class OverlappedGather:
     """
     Double-buffered, asynchronous form of ``gather_smoothed_positions`` for a stream of batches.
 
-    ``launch(sm_mean)`` snapshots the lon/lat rows into a send buffer on the current stream and starts the all-gather
-    with ``async_op=True``: RCCL runs it on its own stream behind the kernels already queued, while the caller goes on
-    to queue the next batch's filter kernels.  Two slots alternate; a slot is waited for just before it is reused, and
-    ``finish()`` drains what is still in flight.  ``result(i)`` is the gathered tensor of the i-th launch (valid after
-    that launch was waited for).
+    ``launch(pos)`` starts the all-gather of one batch's smoothed lon / lat with ``async_op=True``: RCCL runs it on its own
+    stream behind the kernels already queued on the current stream, while the caller goes on to queue the next batch's
+    filter kernels.  ``pos`` is either the smoother's own ``sm_pos`` output ([nrows][2][ntracks], include/ste.h) -- then
+    the collective sends that tensor as it is, no copy -- or a smoothed-mean tensor [nrows][4][b], whose lon / lat rows are
+    first snapshotted into a send buffer (also the route for a short last shard, which is zero-padded to the common width).
+    Two receive slots alternate; a slot is waited for just before it is reused, and ``finish()`` drains what is still in
+    flight.  ``result(i)`` is the gathered tensor of slot i (valid after that launch was waited for).
+
+    ``launch`` returns the receive slot.  After a launch that sent the caller's tensor itself, ``reader_done`` is an event
+    that marks the END of that collective (recorded on a side stream, so the launching stream does not wait): whoever
+    rewrites ``pos`` next -- the batch's next forward pass / smoother -- has to wait for it; ``SmootherPipeline.submit``
+    does, through the value its ``after_smoother`` hook returns (``launch_for_pipeline``).
     """
 
     def __init__(self, nrows: int, ntracks: int, device, dtype=None, group=None):
         import torch
         import torch.distributed as dist
 
+        self.torch = torch
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         dtype = dtype or torch.float64
-        self.send = [torch.empty((nrows, 2, ntracks), dtype=dtype, device=device) for _ in range(2)]
+        self.shape = (nrows, 2, ntracks)
+        self.send = [None, None]  # snapshot buffers, allocated at first need
         self.recv = [torch.empty((self.world, nrows, 2, ntracks), dtype=dtype, device=device) for _ in range(2)]
         self.work = [None, None]
         self.count = 0
+        self.direct = 0  # launches that sent the smoother's own output
+        self.reader_done = None
+        self._on_gpu = torch.device(device).type == "cuda"
+        self._side = torch.cuda.Stream(device) if self._on_gpu else None
+        self._device, self._dtype = device, dtype
 
-    def launch(self, sm_mean):
-        """``sm_mean``: [nrows][4][b] with b <= ntracks (a short last shard is zero-padded to the common width)."""
+    def _snapshot(self, slot, pos):
+        torch = self.torch
+        if self.send[slot] is None:
+            self.send[slot] = torch.empty(self.shape, dtype=self._dtype, device=self._device)
+        b = pos.shape[2]
+        if b == self.shape[2]:
+            self.send[slot].copy_(pos[:, :2, :])
+        else:
+            self.send[slot][:, :, :b].copy_(pos[:, :2, :])
+            self.send[slot][:, :, b:].zero_()
+        return self.send[slot]
+
+    def launch(self, pos):
+        torch = self.torch
         slot = self.count & 1
         if self.work[slot] is not None:
             self.work[slot].wait()  # the current stream now waits for the collective that last used this slot
-        b = sm_mean.shape[2]
-        if b == self.send[slot].shape[2]:
-            self.send[slot].copy_(sm_mean[:, :2, :])
+        if tuple(pos.shape) == self.shape and pos.is_contiguous():
+            src = pos  # sm_pos: the smoother's own output
+            self.direct += 1
         else:
-            self.send[slot][:, :, :b].copy_(sm_mean[:, :2, :])
-            self.send[slot][:, :, b:].zero_()
+            src = self._snapshot(slot, pos)
         out = self.recv[slot]
-        self.work[slot] = self.dist.all_gather_into_tensor(
-            out.view((self.world * out.shape[1],) + tuple(out.shape[2:])), self.send[slot], group=self.group,
-            async_op=True)
+        work = self.dist.all_gather_into_tensor(
+            out.view((self.world * out.shape[1],) + tuple(out.shape[2:])), src, group=self.group, async_op=True)
+        self.work[slot] = work
         self.count += 1
+        self.reader_done = None
+        if src is pos and self._on_gpu:
+            # end of the collective, without making the launching stream wait for it: a side stream waits, an event marks it
+            # (a snapshot is this object's own buffer: nothing of the caller's is still being read then)
+            with torch.cuda.stream(self._side):
+                work.wait()
+                self.reader_done = torch.cuda.Event()
+                self.reader_done.record(self._side)
         return slot
+
+    def launch_for_pipeline(self, pos):
+        """``after_smoother`` hook body for ``SmootherPipeline.submit``: start the gather, hand back the event the next
+        use of ``pos``'s buffers must wait for (None when a snapshot was sent)."""
+        self.launch(pos)
+        return self.reader_done
 
     def finish(self):
         for slot in (0, 1):

@@ -19,12 +19,19 @@ def pytest_configure(config):
 
 def pytest_sessionstart(session):
     """A fresh checkout has no lib/libste_hip.so (built artefacts are not tracked): build it once, the way the driver's
-    build check does, instead of failing every test that loads the C ABI.  hipcc cross-compiles without a GPU."""
+    build check does, instead of failing every test that loads the C ABI.  hipcc cross-compiles without a GPU.  Where
+    there is no hipcc either, the pure-host tests (oracle goldens, host logic, CLI parsing) still run: the tests that load
+    the library then fail on their own with binding.load()'s message."""
     lib = os.path.join(PKG_ROOT, "lib", "libste_hip.so")
     if not os.path.exists(lib):
+        import subprocess
+
         import __graft_entry__
 
-        __graft_entry__.build()
+        try:
+            __graft_entry__.build(check_import=False)
+        except (OSError, subprocess.CalledProcessError) as exc:
+            print(f"[conftest] could not build libste_hip.so ({exc}); tests that load the C ABI will fail", file=sys.stderr)
 
 
 def load_cases(name):

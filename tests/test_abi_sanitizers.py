@@ -19,4 +19,4 @@ def test_abi_tests_pass_under_asan_ubsan(tmp_path):
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_abi.sh"), str(tmp_path)], capture_output=True, text=True,
                        timeout=580)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert "4 passed" in r.stdout
+    assert "6 passed" in r.stdout

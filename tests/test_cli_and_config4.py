@@ -297,6 +297,34 @@ def test_bench_two_rank_control_flow():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
+def test_bench_one_rank_over_rccl():
+    """The N > 1 code path of bench.py with the REAL backend (nccl = RCCL), one rank, as a fresh child process
+    (`--force-dist`): process group on the device, 32 compute units reserved for the collective's kernels, the all-gather
+    of the smoother's own sm_pos output overlapped with the following steps, `all_gather_alone` and `filter_only` in the
+    line.  (More than one RCCL rank cannot share this box's one GPU: the two-rank tests use gloo.)"""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "STE_BENCH_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--tracks", "640", "--steps", "3", "--warmup", "1",
+           "--cpu-tracks", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and "RCCL all-gather" in out["config"]["parallelism"] and out["value"] > 0
+    assert "32 left to the collective's kernels" in out["config"]["pipeline"]
+    ag, fo = out["all_gather_alone"], out["filter_only"]
+    assert ag["ms"] > 0 and ag["bytes_sent_per_rank"] == 501 * 2 * 640 * 8
+    assert fo["value"] > 0 and fo["ms_per_step"] > 0 and out["status_flagged_tracks"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
 def test_bench_line_carries_the_contract():
     """One small N = 1 run of bench.py: exactly one JSON line with every field the driver's contract names -- the metric
     of BASELINE.json, whole-job value, the roofline object of the dominant kernel with its traffic, the CPU baseline of the
@@ -308,7 +336,7 @@ def test_bench_line_carries_the_contract():
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "2", "--tracks", "640",
-           "--cpu-tracks", "64", "--cpu-pool-tracks", "0", "--no-gp"]
+           "--cpu-tracks", "64", "--cpu-pool-tracks", "0", "--no-gp", "--fleet-tracks", "1500", "--fleet-chunk", "500"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -321,7 +349,15 @@ def test_bench_line_carries_the_contract():
     assert abs(out["value"] - 640 * 500 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     r = out["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0 and r["launch_ms"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0
+    # achieved = 512 algorithmic bytes per track-step x the track-steps/s of the timed region
+    assert abs(r["achieved"] - 512 * out["value"] / 1e9) < 1e-6 * r["achieved"] and r["algorithmic_bytes_per_track_step"] == 512
+    pl = r["per_launch"]  # one launch of the dominant kernel over its own HIP-event duration
+    assert pl["kernel"] == "ukf_forward" and pl["launch_ms"] > 0 and pl["launches_in_flight"] >= 1
+    assert abs(pl["achieved"] - 192 * 640 * 500 / (pl["launch_ms"] * 1e-3) / 1e9) < 1e-6 * pl["achieved"]
+    fl = out["extra"]["fleet_100k"]  # the product entry point for a fleet, on a small one here
+    assert fl["bit_identical_to_one_launch"] is True and fl["track_steps"] == 1500 * 500 and fl["value"] > 0
+    assert fl["gpu_vs_oracle"]["means_smoothed_max_rel_err"] < 1e-6 and fl["flagged_tracks"] == 0
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["unit"] == "track-steps/s"
     par = c["gpu_vs_oracle"]

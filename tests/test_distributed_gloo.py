@@ -49,6 +49,14 @@ def _worker(rank, world, port, total, q):
         slots = [og.launch(local + float(i)) for i in range(3)]
         og.finish()
         assert torch.equal(og.result(slots[2]), g + 2.0) and torch.equal(og.result(slots[1]), g + 1.0)
+        assert og.direct == 0  # [N+1][4][B] tensors: lon / lat snapshotted into a send buffer
+        # the smoother's own sm_pos output ([N+1][2][B], include/ste.h) is sent as it is: same result, no snapshot
+        pos = local[:, :2, :].contiguous()
+        slot = og.launch(pos)
+        og.finish()
+        assert og.direct == 1 and og.send[slot] is not pos and torch.equal(og.result(slot), g)
+        assert og.launch_for_pipeline(pos) is None  # no GPU stream to order against on the CPU backend
+        og.finish()
         q.put((rank, lo, hi, g.numpy()))
         dist.barrier()
     finally:

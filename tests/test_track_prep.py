@@ -5,12 +5,13 @@ Sphere model (haversine_formula + heading): pinned to arrays produced by RUNNING
 (tests/golden/track_prep.npz, made by tests/golden/make_golden.py ``prep_cases``: 40 ragged random tracks, duplicate
 timestamps, the 0/360 seam).  WGS84 model: geographiclib is not installed anywhere this runs, so beyond the one noise-free
 number the reference's CLI fixture holds (row 0) the WGS84 results are **parity unpinned**; those tests compare the
-device with this package's own host Vincenty and say so in their names.
+device with this package's own host restatement of Karney's algorithm (track_estimators/geodesic.py) and say so in their names.
 
 Floating-point tolerance: the device evaluates the same formulas with its own libm and contracted FMAs; distances and
 headings agree to ~1e-13 relative, and the rates -- differences of neighbouring values divided by the gap -- to 1e-9
 absolute at the magnitudes of these tracks.  Non-finite values (duplicate timestamps, gap = 0) must match exactly.
 """
+import math
 import os
 
 import numpy as np
@@ -168,20 +169,32 @@ def test_prep_wgs84_unpinned_feeds_filter_end_to_end():
         assert np.max(np.abs(a - c) / np.maximum(np.abs(a), 1e-12)) < 1e-6
 
 
-def test_prep_wgs84_flags_legs_vincenty_cannot_solve():
-    """A nearly antipodal leg (where Vincenty's iteration does not contract, but the reference's geographiclib would still
-    answer): the device sets STE_PREP_STATUS_NOCONV for that track only, the Python wrapper warns and hands the bit back;
-    the sphere model never flags."""
-    lons = [np.array([0.0, 1.0, 2.0]), np.array([0.0, 179.7, 179.9]), np.array([10.0, 10.5, 11.0])]
-    lats = [np.array([0.0, 1.0, 2.0]), np.array([0.0, 0.2, 0.4]), np.array([50.0, 50.5, 51.0])]
-    gaps = [np.ones(2), np.ones(2), np.ones(2)]
-    with pytest.warns(RuntimeWarning, match=r"track\(s\) \[1\]"):
-        res = batch.prepare_observations(lons, lats, gaps, model="wgs84")
-    assert [r["status"] for r in res] == [0, 1, 0]
-    assert np.all(np.isfinite(res[0]["sog"])) and np.all(np.isfinite(res[2]["sog"]))
+def test_prep_wgs84_solves_nearly_antipodal_legs():
+    """Nearly antipodal legs -- which the Vincenty iteration of rounds 1-3 flagged instead of solving -- and meridional,
+    equatorial and polar ones: the device's Karney solver agrees with the host's (track_estimators/geodesic.py, checked on
+    its own in tests/test_geodesic_karney.py) to 1e-9 km and, where the azimuth is well conditioned, 1e-9 deg; no status
+    bit, no warning."""
     import warnings
 
+    from track_estimators import geodesic
+
+    rng = np.random.default_rng(3)
+    lons, lats, gaps = [], [], []
+    for _ in range(64):
+        la, lo = rng.uniform(-80, 80), rng.uniform(-180, 180)
+        lons.append(np.array([lo, lo + 180 + rng.uniform(-0.6, 0.6), lo + rng.uniform(-1, 1)]))
+        lats.append(np.array([la, -la + rng.uniform(-0.6, 0.6), la + rng.uniform(-1, 1)]))
+        gaps.append(np.ones(2))
+    lons += [np.array([0.0, 179.7, 179.9]), np.array([5.0, 5.0, 5.0]), np.array([-30.0, 100.0, -100.0]), np.array([0.0, 180.0, 0.0])]
+    lats += [np.array([0.0, 0.2, 0.4]), np.array([-40.0, 60.0, 89.9]), np.array([0.0, 0.0, 0.0]), np.array([89.9, 89.9, -89.9])]
+    gaps += [np.ones(2)] * 4
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        res = batch.prepare_observations(lons, lats, gaps, model="sphere")
-    assert [r["status"] for r in res] == [0, 0, 0]
+        res = batch.prepare_observations(lons, lats, gaps, model="wgs84")
+    assert [r["status"] for r in res] == [0] * len(res)
+    for r, lon, lat in zip(res, lons, lats):
+        for j in range(2):
+            s12, azi1, _, _ = geodesic.inverse(lat[j], lon[j], lat[j + 1], lon[j + 1])
+            assert abs(r["sog"][j] - s12 * 1e-3) < 1e-9, (lon, lat, j)
+            cond = abs(math.sin(min(s12, 2.0e7 - s12) / 6.4e6))  # azimuths at the antipode move by degrees per micrometre
+            assert abs((r["cog"][j] - azi1 + 180.0) % 360.0 - 180.0) * cond < 1e-9, (lon, lat, j)
