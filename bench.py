@@ -56,7 +56,7 @@ BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mea
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
 FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
 # rocprofv3 PMC summary of this command for the current kernel generation (see profiles/README.md for the passes)
-COUNTERS_CSV = os.path.join(ROOT, "profiles", "r03_counters_per_track_step.csv")
+COUNTERS_CSV = os.path.join(ROOT, "profiles", "r04_counters_per_track_step.csv")
 EVENT_EVERY = 4  # steps between two steps whose kernels are bracketed by HIP events (see the timed loop)
 
 
@@ -246,7 +246,7 @@ def measure_config3(dev, reps: int = 3):
                     "duplicate timestamps and end non-finite exactly where the reference raises LinAlgError"}
 
 
-def measure_fleet(dev, ntracks: int = 100_000, chunk: int = TRACKS_CONFIG1, reps: int = 3, sample: int = 48):
+def measure_fleet(dev, ntracks: int = 100_000, chunk=None, reps: int = 3, sample: int = 48):
     """BASELINE.json configs[2]'s job on ONE GPU through the product's entry point: `ntracks` DISTINCT synthetic tracks x 500
     steps, resident in HBM, through batch.run_fleet (windows of one resident fleet through the pipelined kernels; results
     stay in the fleet's tensors) -- beside the same job as one DeviceBatch.run() (one forward launch of 1 563 waves on
@@ -256,6 +256,7 @@ def measure_fleet(dev, ntracks: int = 100_000, chunk: int = TRACKS_CONFIG1, reps
 
     from oracle import ukf_oracle as orc
 
+    chunk = chunk or batch.FLEET_CHUNK
     H, Q, R, P0 = synthetic.example_matrices()
     t0 = time.perf_counter()
     sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=50_000_000)
@@ -352,7 +353,7 @@ def _main(stack):
                     help="time slices per pipelined forward pass (default: batch.DEFAULT_SLICES)")
     ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
     ap.add_argument("--fleet-tracks", type=int, default=100_000)
-    ap.add_argument("--fleet-chunk", type=int, default=TRACKS_CONFIG1, help="window size of the fleet entry (tests)")
+    ap.add_argument("--fleet-chunk", type=int, default=None, help="window size of the fleet entry (default: batch.FLEET_CHUNK)")
     ap.add_argument("--no-gp", action="store_true",
                     help="skip the `extra.gp_config4` entry (BASELINE configs[4]: one batched GP objective at 1000 x 2000, "
                          "measured after the timed region at --gpus 1)")
@@ -744,6 +745,8 @@ def _main(stack):
             # driver's default run measures it too (bench_gp.py alone prints the same object, with --fit for a whole fit)
             import bench_gp
 
+            if pipe is not None:
+                pipe.close()  # its streams own hardware queues, and the fleet entry below builds a pipeline of its own
             del dbs, db, pipe
             torch.cuda.empty_cache()
             try:
@@ -755,6 +758,11 @@ def _main(stack):
             except Exception as exc:
                 out["extra"]["config3_modern_ships_robust"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_fleet and args.cpu_tracks > 0:
+            try:
+                if pipe is not None:
+                    pipe.close()
+            except NameError:
+                pass
             dbs, db, pipe = [], None, None
             torch.cuda.empty_cache()
             try:

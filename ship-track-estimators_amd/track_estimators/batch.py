@@ -698,6 +698,15 @@ class SmootherPipeline:
         # destroyed while everything is still up: close() / the context manager / __del__, and at the latest atexit.
         _live_pipelines.add(self)
         _register_atexit()
+        # Every stream of a pipeline owns a hardware queue.  Past ~16 of them in a process the firmware multiplexes queues and
+        # launches crawl (a 100 000-track fleet: 8.9 ms on 10 + 6 streams, 12.0 on 13 + 8, 28 on 16 + 8; profiles/r04_fleet_sweep.txt).
+        nq = sum(len(q.fwd_streams) + len(q.bwd_streams) for q in _live_pipelines)
+        if nq > MAX_PIPELINE_QUEUES:
+            import warnings
+
+            warnings.warn(f"{nq} pipeline streams are alive in this process (more than {MAX_PIPELINE_QUEUES}): each owns a hardware "
+                          "queue, and beyond that many the GPU multiplexes them and every launch slows down; close() the "
+                          "pipelines that are no longer used", RuntimeWarning, stacklevel=2)
 
     # single-stream names kept for callers that look at them
     @property
@@ -822,8 +831,13 @@ class SmootherPipeline:
 
 _live_pipelines = weakref.WeakSet()
 _atexit_registered = False
-# time slices per pipelined forward pass when SmootherPipeline is not told (see SmootherPipeline.__init__)
+# Time slices per pipelined forward pass when SmootherPipeline is not told.  One: slices are bit-identical and let the waves
+# of the passes in flight re-balance at every boundary, but a stream's next slice waits for ALL waves of the one before, and
+# with every window advancing in step no smoother has anything to do until the end -- measured (10 000-track batches, 7 + 6
+# streams): 0.672 / 0.715 / 0.768 ms per step at 1 / 2 / 4 slices over 100 steps, 0.804 / 0.781 / 0.819 at the driver's 20;
+# a 100 000-track fleet: 8.6 / 8.6 / 8.5 ms (profiles/r04_pipeline_sweeps.txt, r04_fleet_sweep.txt).
 DEFAULT_SLICES = 1
+MAX_PIPELINE_QUEUES = 16
 
 
 def _close_live_pipelines():
@@ -971,13 +985,19 @@ def fleet_windows(ntracks: int, chunk: int):
     return [(lo, min(lo + w, ntracks)) for lo in range(0, ntracks, w)]
 
 
-def run_fleet(fleet, chunk: int = 10_000, device="cuda:0", smooth: bool = True, outputs=None, pipeline=None,
+# Window size of run_fleet when the caller names none: 256 waves of 64 tracks, a quarter of the chip's 1 024 SIMDs, so that
+# whole windows make up a chip-full of forward waves.  Measured on a resident 100 000 x 500 fleet
+# (profiles/r04_fleet_sweep.txt): 7 windows of 14 336 tracks 8.5 ms, 10 of 10 048 9.1 ms, 13 of 7 744 9.2 ms, one launch 9.5 ms.
+FLEET_CHUNK = 16_384
+
+
+def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = True, outputs=None, pipeline=None,
               slices: Optional[int] = None, sm_pos: bool = False):
     """
     UKF + URTSS over a fleet of any size -- the batch dimension of the reference's example loop
     (examples/example_ukf_rts_smoother_batch.py:19-90, one ship at a time) at the rate the pipelined kernels sustain.
 
-    The fleet is cut into windows of about ``chunk`` tracks (length-bucketed: ``pack_tracks`` lays tracks out longest
+    The fleet is cut into windows of at most ``chunk`` tracks, all nearly the same size (length-bucketed: ``pack_tracks`` lays tracks out longest
     first).  Windows are not copies: a window is the fleet's own tensors seen through a batch struct with
     ``track_stride`` = the fleet's width (include/ste.h), so every window's kernels read the fleet's inputs and write the
     fleet's histories in place.  The windows go through a ``SmootherPipeline``: the forward passes of several windows share

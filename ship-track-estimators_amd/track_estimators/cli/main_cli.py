@@ -13,6 +13,9 @@ Opt-in keys of ``input.json`` beyond the reference's (absent = the reference's b
   ``"chi_alpha": 50.0``   its threshold (the reference hard-codes 50, unscented.py:357)
   ``"geodesy": "sphere"`` speed / course over ground from ``haversine_formula`` / ``heading`` (utils.py:75-147) instead of
                           the WGS84 pair ``ShipTrack`` defaults to
+  ``"drop_duplicate_times": true``  rows whose (hour-resolution) timestamp repeats the row before are dropped on reading
+                          (``ShipTrack.read_csv(drop_duplicate_times=True)``): five of the seven data/modern_ships ids carry
+                          such rows and end non-finite without it, in the reference (LinAlgError) as here (status NaN)
 """
 from __future__ import annotations
 
@@ -79,8 +82,9 @@ def get_input_settings(settings: dict) -> Tuple:
     return dim, dt, nsteps, H, Q, R, P, smooth_control
 
 
-def get_optional_settings(settings: dict) -> Tuple[bool, float, str]:
-    """(robust, chi_alpha, geodesy): the opt-in keys this CLI adds to the reference's input.json (module docstring)."""
+def get_optional_settings(settings: dict) -> Tuple[bool, float, str, bool]:
+    """(robust, chi_alpha, geodesy, drop_duplicate_times): the opt-in keys this CLI adds to the reference's input.json
+    (module docstring)."""
     robust = settings.get("robust", False)
     if not isinstance(robust, bool):
         raise ValueError(f"'robust' must be true or false, got {robust!r}")
@@ -90,17 +94,20 @@ def get_optional_settings(settings: dict) -> Tuple[bool, float, str]:
     geodesy = settings.get("geodesy", "wgs84")
     if geodesy not in ("wgs84", "sphere"):
         raise ValueError(f"'geodesy' must be \"wgs84\" or \"sphere\", got {geodesy!r}")
-    return robust, chi_alpha, geodesy
+    dedup = settings.get("drop_duplicate_times", False)
+    if not isinstance(dedup, bool):
+        raise ValueError(f"'drop_duplicate_times' must be true or false, got {dedup!r}")
+    return robust, chi_alpha, geodesy, dedup
 
 
-def _prepare_track(args, ship_id, smooth_control, geodesy="wgs84"):
+def _prepare_track(args, ship_id, smooth_control, geodesy="wgs84", dedup=False):
     """ShipTrack -> measurements, rates and prior exactly as main_cli.py:89-109 does."""
     if geodesy == "sphere":
         ship_track = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
     else:
         ship_track = ShipTrack(calc_distance_func=geographiclib_distance, calc_heading_func=geographiclib_heading)
     ship_track.read_csv(args.track_file, ship_id=ship_id, id_col=args.id_col, lat_col=args.lat_id, lon_col=args.lon_id,
-                        reverse=bool(args.reverse))
+                        reverse=bool(args.reverse), drop_duplicate_times=dedup)
     if smooth_control not in [-1, 0, 1, None]:
         logger.info(f"Smoothing SOG and COG by {smooth_control}.")
         ship_track.calculate_cog()
@@ -140,12 +147,12 @@ def track_estimator(argv=None):
     logger.info(f"Reading input JSON from '{args.input_file}'...")
     settings = load_input_json(args.input_file)
     dim, dt, nsteps, H, Q, R, P, smooth_control = get_input_settings(settings)
-    robust, chi_alpha, geodesy = get_optional_settings(settings)
+    robust, chi_alpha, geodesy, dedup = get_optional_settings(settings)
     substeps = nsteps if dt in [-1, 0, None] else 1  # a positive constant dt is ignored, like main_cli.py:114-120
 
     ship_ids = [s for s in str(args.ship_id).split(",") if s] if "," in str(args.ship_id) else [args.ship_id]
     if len(ship_ids) == 1 and not robust:
-        ship_track, x0 = _prepare_track(args, ship_ids[0], smooth_control, geodesy)
+        ship_track, x0 = _prepare_track(args, ship_ids[0], smooth_control, geodesy, dedup)
         dt_array = generate_dts(ship_track.dts, substeps)
         logger.info("Running the Unscented Kalman Filter.")
         ukf = UnscentedKalmanFilter(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
@@ -161,7 +168,7 @@ def track_estimator(argv=None):
 
         tracks, x0s, dts = [], [], []
         for sid in ship_ids:
-            st, x0 = _prepare_track(args, sid, smooth_control, geodesy)
+            st, x0 = _prepare_track(args, sid, smooth_control, geodesy, dedup)
             tracks.append(st)
             x0s.append(x0[:, 0])
             dts.append(generate_dts(st.dts, substeps))

@@ -44,13 +44,19 @@ class ShipTrack:
             self.z = self.get_measurements()
 
     def read_csv(self, csv_file: str, ship_id: Optional[Union[str, int]] = None, id_col: str = "id",
-                 lat_col: str = "lat", lon_col: str = "lon", reverse: bool = False):
+                 lat_col: str = "lat", lon_col: str = "lon", reverse: bool = False, drop_duplicate_times: bool = False):
         """
         Load the rows of ``ship_id`` from ``csv_file`` (columns ``yr, mo, dy, hr`` + id/lat/lon columns).
 
         Follows ship_track.py:139-195 including its quirks: the id column and ``ship_id`` are compared as strings
         (``str(None) == 'None'`` filters too), rows keep file order (index sort only), timestamps are built as
         ``yr-mo-dyThh:00:00`` and ``dts`` are the gaps in hours.  Returns ``(lat, lon, dts)``.
+
+        ``drop_duplicate_times`` (an extra of this package, default off = the reference's behaviour): drop every row whose
+        timestamp equals that of the row before it.  Hour-resolution timestamps repeat in real logs (five of the seven
+        ships of data/modern_ships); a zero gap makes sog = distance / 0 (ship_track.py:217) and the filter ends in NaN /
+        LinAlgError.  With the switch on a file reads as the same file with those rows deleted would
+        (tests/golden/modern_ships_dedup.npz: the reference run on such files).
         """
         df = pd.read_csv(csv_file)
         df[id_col] = df[id_col].astype(str)
@@ -62,6 +68,9 @@ class ShipTrack:
         stamp = df["yr"].astype(str) + "-" + df["mo"].astype(str) + "-" + df["dy"].astype(str)
         stamp = stamp + "T" + df["hr"].astype(str).str.zfill(2) + ":00:00"
         df = df.assign(date=stamp)
+        if drop_duplicate_times:
+            when = pd.to_datetime(df.date)
+            df = df.loc[(when != when.shift(1)).values].reset_index(drop=True)
         self.df = df
         self.dates = pd.to_datetime(df.date).to_list()
         gaps = [pd.Timedelta(self.dates[i + 1] - self.dates[i]).total_seconds() / 3600.0

@@ -377,6 +377,62 @@ def modern_robust_cases():
     return out
 
 
+def modern_dedup_cases():
+    """BASELINE configs[3] beyond the two ships the reference can filter as they are: the five ids with duplicate
+    timestamps, each read by the REFERENCE's ShipTrack from a file in which the rows that repeat the timestamp of the row
+    before were deleted (what this package's opt-in ``drop_duplicate_times`` does on reading), then run with outlier
+    rejection on (``_RobustUKF``) and zero noise.  Sampled rows as in modern_cases.  A ship the reference still cannot
+    filter is recorded as such."""
+    import tempfile
+
+    import pandas as pd
+
+    csv = "/root/reference/data/modern_ships/modern_ship_data.csv"
+    H = np.diag([1, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6]); P = np.eye(4)
+    out = {}
+    ids = ["WDG7520", "WDA7827", "WGAE", "KAOU", "SJA4RSK"]
+    df = pd.read_csv(csv)
+    for sid in ids:
+        d = df.loc[df["id"].astype(str) == sid]
+        stamp = d["yr"].astype(str) + "-" + d["mo"].astype(str) + "-" + d["dy"].astype(str) + "T" + d["hr"].astype(str)
+        d = d.loc[(stamp != stamp.shift(1)).values]
+        with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as f:
+            d.to_csv(f, index=False)
+            tmp = f.name
+        try:
+            st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+            st.read_csv(tmp, ship_id=sid, id_col="id", lat_col="lat", lon_col="lon")
+        finally:
+            os.unlink(tmp)
+        st.get_measurements(include_sog=True, include_cog=True)
+        st.calculate_cog_rate()
+        st.calculate_sog_rate()
+        out[f"{sid}_T"] = np.int64(len(st.lon))
+        out[f"{sid}_dropped"] = np.int64(int((df["id"].astype(str) == sid).sum()) - len(st.lon))
+        assert not (st.dts == 0).any()
+        x0 = st.z[:, 0].reshape(-1, 1).copy()
+        ukf = _RobustUKF(H=H, Q=Q, R=R, P=P, x0=x0, non_linear_process=geodetic_dynamics)
+        dt = generate_dts(st.dts, 2)
+        N = len(dt)
+        try:
+            with NoisePatch("zero"), contextlib.redirect_stdout(io.StringIO()):
+                means, covs = ukf.run(nsteps=N, dt=dt, ship_track=st)
+                sm, sc = ukf.run_rts_smoother(ship_track=copy.deepcopy(st))
+        except (np.linalg.LinAlgError, IndexError, ValueError) as e:
+            out[f"{sid}_ok"] = np.int64(0)
+            print(f"modern dedup {sid}: {type(e).__name__} {e}")
+            continue
+        finite = bool(np.isfinite(means).all() and np.isfinite(sm).all())
+        rows = np.unique(np.concatenate([np.arange(0, N + 1, 50), np.arange(N - 19, N + 1)]))
+        out[f"{sid}_ok"] = np.int64(1 if finite else 0)
+        out[f"{sid}_rows"] = rows
+        for k, v in (("means", means), ("covs", covs), ("means_smoothed", sm), ("covs_smoothed", sc)):
+            out[f"{sid}_{k}"] = v[rows]
+        print(f"modern dedup {sid}: T={len(st.lon)} N={N} finite={finite}")
+    out["ids"] = np.array(ids)
+    return out
+
+
 def prep_cases():
     """Observation preparation: the reference's ShipTrack.calculate_cog / calculate_sog /
     calculate_sog_rate / calculate_cog_rate / get_measurements(True, True) (ship_track.py:197-338) with its own pure-NumPy
@@ -741,6 +797,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **robust_cases())
     np.savez_compressed(os.path.join(HERE, "modern_ships_robust.npz"), **modern_robust_cases())
+    np.savez_compressed(os.path.join(HERE, "modern_ships_dedup.npz"), **modern_dedup_cases())
     np.savez_compressed(os.path.join(HERE, "track_prep.npz"), **prep_cases())
     np.savez_compressed(os.path.join(HERE, "batch_examples.npz"), **example_cases())
     np.savez_compressed(os.path.join(HERE, "cli_smooth.npz"), **smooth_case())
@@ -751,7 +808,7 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
-SELECTABLE = {"robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
+SELECTABLE = {"modern_dedup": (modern_dedup_cases, "modern_ships_dedup.npz"), "robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
               "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz"),
               "smooth": (smooth_case, "cli_smooth.npz"), "savgol": (savgol_case, "savgol_example.npz"),
               "illcond": (lambda: pack_cases(illcond_cases()), "ukf_illcond.npz")}

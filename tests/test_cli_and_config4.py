@@ -269,6 +269,45 @@ def test_config4_modern_ships_robust_on():
 
 
 @pytest.mark.gpu
+def test_config4_modern_ships_deduplicated_robust_on():
+    """The five ids of data/modern_ships whose hour-resolution timestamps repeat (zero gaps: the reference dies with
+    LinAlgError, this package flags them) with ``ShipTrack.read_csv(drop_duplicate_times=True)`` -- an opt-in extra of this
+    package -- and outlier rejection on, against the REFERENCE run on files from which those rows were deleted
+    (tests/golden/modern_ships_dedup.npz, made by make_golden.modern_dedup_cases).  configs[3]'s full-length parity no
+    longer rests on WCE5063 alone."""
+    from track_estimators import batch
+    from track_estimators.ship_track import ShipTrack
+    from track_estimators.utils import generate_dts, haversine_formula, heading
+
+    g = np.load(os.path.join(GOLDEN, "modern_ships_dedup.npz"))
+    csv = os.path.join(GOLDEN, "data", "modern_ship_data.csv.gz")
+    H = np.diag([1.0, 1, 0, 0]); R = np.diag([0.25, 0.25, 0, 0]); Q = np.diag([1e-4, 1e-4, 1e-6, 1e-6]); P = np.eye(4)
+    ids = [str(s) for s in g["ids"]]
+    tracks, dts, x0s = [], [], []
+    for sid in ids:
+        st = ShipTrack(calc_distance_func=haversine_formula, calc_heading_func=heading)
+        st.read_csv(csv, ship_id=sid, id_col="id", lat_col="lat", lon_col="lon", drop_duplicate_times=True)
+        assert len(st.lon) == int(g[f"{sid}_T"]) and not (st.dts == 0).any() and int(g[f"{sid}_dropped"]) > 0
+        z = st.get_measurements(include_sog=True, include_cog=True)
+        st.calculate_cog_rate()
+        st.calculate_sog_rate()
+        tracks.append(st)
+        dts.append(generate_dts(st.dts, 2))
+        x0s.append(z[:, 0])
+    hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P)
+    hb.robust = True
+    out = batch.run_fleet(hb)
+    checked = 0
+    for b, sid in enumerate(ids):
+        if not int(g[f"{sid}_ok"]):
+            continue
+        assert not (out["status"][b] & 0x1), sid
+        _check_against(out, b, sid, g, int(g[f"{sid}_stable_row"]) if f"{sid}_stable_row" in g.files else 1 << 30)
+        checked += 1
+    assert checked >= 2
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_bench_two_rank_control_flow():
     """bench.py launched as two ranks by torch.distributed.run (as the driver does for N>1), both on this box's one GPU
@@ -420,9 +459,10 @@ def test_bench_self_launch_command(monkeypatch):
 def test_cli_optional_keys_parse_and_validate():
     from track_estimators.cli.main_cli import get_optional_settings
 
-    assert get_optional_settings({}) == (False, 50.0, "wgs84")  # absent = the reference's behaviour
-    assert get_optional_settings({"robust": True, "chi_alpha": 30, "geodesy": "sphere"}) == (True, 30.0, "sphere")
-    for bad in ({"robust": "yes"}, {"chi_alpha": 0}, {"geodesy": "flat"}):
+    assert get_optional_settings({}) == (False, 50.0, "wgs84", False)  # absent = the reference's behaviour
+    assert get_optional_settings({"robust": True, "chi_alpha": 30, "geodesy": "sphere", "drop_duplicate_times": True}) == (
+        True, 30.0, "sphere", True)
+    for bad in ({"robust": "yes"}, {"chi_alpha": 0}, {"geodesy": "flat"}, {"drop_duplicate_times": 1}):
         with pytest.raises(ValueError):
             get_optional_settings(bad)
 

@@ -195,8 +195,8 @@ def test_single_function_kernels():
 
 def test_full_size_batch_properties():
     """BASELINE.json configs[1] at full size (10 000 tracks x 500 steps) through size-independent properties:
-    no status flags, identical tracks in different batch slots give identical bits, the two lane mappings agree, and a
-    sample of tracks matches the oracle."""
+    no status flags, identical tracks in different batch slots give identical bits, the two lane mappings agree, and 256
+    tracks match the oracle in all four histories (filtered and smoothed, means and covariances) for both mappings."""
     from oracle import ukf_oracle as orc
     from track_estimators import batch, synthetic
 
@@ -207,7 +207,7 @@ def test_full_size_batch_properties():
     sb = synthetic.SyntheticBatch(**{f.name: getattr(sbu, f.name)[idx] for f in __import__("dataclasses").fields(sbu)})
     hb = batch.pack_uniform(sb, 4, H, Q, R, P0)
     assert hb.B == B and hb.Nmax == 500
-    res = {}
+    res, full, nchk = {}, {}, 256
     for lanes in (1, 4):
         hb.lanes = lanes
         db = batch.DeviceBatch(hb)
@@ -215,6 +215,7 @@ def test_full_size_batch_properties():
         db.torch.cuda.synchronize()
         assert not db.status_host().any()
         res[lanes] = db.sm_mean.cpu().numpy()  # [N+1][4][B]
+        full[lanes] = db.download(("means", "covs", "means_smoothed", "covs_smoothed"), db.torch.arange(nchk, device=db.device))
         first = np.full(nuniq, -1)
         for slot, src in enumerate(idx):
             if first[src] < 0:
@@ -224,15 +225,19 @@ def test_full_size_batch_properties():
         del db
     a, b = res[1], res[4]
     assert np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-12)) < 1e-7
-    n = 48
+    n = nchk
     fires = hb.upd_idx.T[:n] >= 0
     zidx = np.where(fires, hb.upd_idx.T[:n], 0)
     ridx = np.cumsum(fires, axis=1) - fires
     m, P = orc.forward_batch(hb.x0.T[:n], P0, H, Q, R, hb.dt.T[:n], fires, zidx, ridx, sb.z[:n], sb.sog_rate[:n], sb.cog_rate[:n])
     rr = np.broadcast_to(batch.rts_rate_index(501, 125, 126), (n, 500))
-    sm, _ = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
+    sm, sP = orc.backward_batch(m, P, Q, hb.dt.T[:n], rr, sb.sog_rate[:n], sb.cog_rate[:n])
     got = res[4][:, :, :n].transpose(2, 0, 1)
     assert mean_err(got, sm) < MEAN_TOL
+    for lanes in (1, 4):  # all four histories at full size (was smoothed means of 48 tracks)
+        f = full[lanes]
+        assert mean_err(f["means"], m) < MEAN_TOL and mean_err(f["means_smoothed"], sm) < MEAN_TOL, lanes
+        assert cov_err(f["covs"], P) < COV_TOL and cov_err(f["covs_smoothed"], sP) < COV_TOL, lanes
 
 
 def test_degenerate_shapes():

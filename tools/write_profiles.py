@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/r03_counters_per_track_step.csv and r03_pmc_counters_per_launch.csv from the rocprofv3 --pmc passes of
-profiles/tools/pmc_passes_r03.sh (usage: tools/write_r03_profiles.py gpurun_out/<pmc dir>)."""
+"""profiles/rNN_counters_per_track_step.csv and rNN_pmc_counters_per_launch.csv from the rocprofv3 --pmc passes of
+profiles/tools/pmc_passes_rNN.sh (usage: tools/write_profiles.py gpurun_out/<pmc dir> [round, default 04])."""
 import collections
 import csv
 import glob
@@ -9,6 +9,7 @@ import shutil
 import sys
 
 root = sys.argv[1]
+RN = "r" + (sys.argv[2] if len(sys.argv) > 2 else "04")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -24,11 +25,11 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 names = sorted({n for k in acc for n in acc[k]})
 if not acc or not all(k in acc for _, k in [("f", "ste::ukf_forward_l1<true, true>")]):
-    sys.exit(f"no counter files of the round-3 kernels under {root}: nothing written")
+    sys.exit(f"no counter files of the filter kernels under {root}: nothing written")
 TS = 5.0e6
-with open("profiles/r03_pmc_counters_per_launch.csv", "w") as f:
+with open(f"profiles/{RN}_pmc_counters_per_launch.csv", "w") as f:
     f.write("# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp\n")
-    f.write("# (profiles/tools/pmc_passes_r03.sh: one pass per counter group, never combined with other trace domains); round-3 kernels,\n")
+    f.write("# (profiles/tools/pmc_passes_" + RN + ".sh: one pass per counter group, never combined with other trace domains); kernels of round " + RN + ",\n")
     f.write("# 10 000 tracks x 500 steps = 5.0e6 track-steps per launch; average of every counter over the launches of each kernel;\n")
     f.write("# ms = average dispatch duration while counting (counter runs serialise kernels: these are alone-on-the-chip times)\n")
     f.write("kernel,launches,ms," + ",".join(names) + "\n")
@@ -37,10 +38,10 @@ with open("profiles/r03_pmc_counters_per_launch.csv", "w") as f:
         f.write('"%s",%d,%.3f,' % (k, len(dur[k]), sum(dur[k]) / len(dur[k])) + ",".join(("%.1f" % c[n]) if n in c else "" for n in names) + "\n")
 rows = [("ukf_forward", "ste::ukf_forward_l1<true, true>"), ("urtss_backward", "ste::urtss_recur_l1<false>"),
         ("ukf_forward_q4", "ste::ukf_forward_q4<true, false>")]
-with open("profiles/r03_counters_per_track_step.csv", "w") as f:
-    f.write("# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp   (round 3 kernels, 10 000 tracks x 500 steps\n")
-    f.write("# = 5.0e6 track-steps per launch; one --pmc pass per counter group (profiles/tools/pmc_passes_r03.sh), averages over the launches of each kernel; raw\n")
-    f.write("# averages: profiles/r03_pmc_counters_per_launch.csv).  hbm_read = FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count, profiles/README.md),\n")
+with open(f"profiles/{RN}_counters_per_track_step.csv", "w") as f:
+    f.write("# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp   (kernels of round " + RN + ", 10 000 tracks x 500 steps\n")
+    f.write("# = 5.0e6 track-steps per launch; one --pmc pass per counter group (profiles/tools/pmc_passes_" + RN + ".sh), averages over the launches of each kernel; raw\n")
+    f.write("# averages: profiles/" + RN + "_pmc_counters_per_launch.csv).  hbm_read = FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count, profiles/README.md),\n")
     f.write("# hbm_write = WRITE_SIZE KiB x 1024, fp64_flops = (ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) wave-instructions x 64 lanes, all / 5.0e6.\n")
     f.write("# ukf_forward = the lane-per-track kernel the default (pipelined) run launches; ukf_forward_q4 = the quad-per-track kernel a batch on its\n")
     f.write("# own gets at this size (bench.py's `serial` leg); urtss_backward = the recurrence smoother (one lane per track, gain solve + recurrence).\n")
@@ -53,9 +54,9 @@ with open("profiles/r03_counters_per_track_step.csv", "w") as f:
         f.write('%s,"%s",%.2f,%.2f,%.1f,%.1f,%.1f,%.1f,%d,%.3f\n' % (
             short, k, c["FETCH_SIZE"] * 2048 / TS, c["WRITE_SIZE"] * 1024 / TS, flops, c["SQ_INSTS_VALU"] / w / 500,
             c["SQ_INSTS_SALU"] / w / 500, sum(f64) / w / 500, w, sum(dur[k]) / len(dur[k])))
-for src, dst in (("stats/runc/*kernel_stats.csv", "profiles/r03_pipelined_kernel_stats.csv"), ("bench_k100.json", "profiles/r03_bench_default.json"),
-                 ("bench_driver_form.json", "profiles/r03_bench_driver_form.json")):
+for src, dst in (("stats/runc/*kernel_stats.csv", f"profiles/{RN}_pipelined_kernel_stats.csv"), ("bench_k100.json", f"profiles/{RN}_bench_default.json"),
+                 ("bench_driver_form.json", f"profiles/{RN}_bench_driver_form.json")):
     m = glob.glob(os.path.join(root, src))
     if m:
         shutil.copy(m[0], dst)
-print(open("profiles/r03_counters_per_track_step.csv").read())
+print(open(f"profiles/{RN}_counters_per_track_step.csv").read())
