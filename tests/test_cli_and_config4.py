@@ -297,14 +297,29 @@ def test_config4_modern_ships_deduplicated_robust_on():
     hb = batch.pack_tracks(tracks, dts, x0s, H, Q, R, P)
     hb.robust = True
     out = batch.run_fleet(hb)
-    checked = 0
+    # The fixture says, row by row, how far ONE change inside the reference's own arithmetic (eigen instead of Schur square
+    # root: the same matrix function to 1e-15) moves each history of that ship.  Where that is < 1e-8 -- every sampled row
+    # of three ships, 94 % and 58 % of the other two -- the north-star tolerances are asserted; the remaining rows sit in
+    # episodes where rounding decides (a ship at rest, the rejection threshold crossed or not) and move by 1e-5 .. 1e-4 for
+    # ANY implementation that does not reproduce LAPACK's rounding: held to 1e-3 there.
+    strict_rows = 0
     for b, sid in enumerate(ids):
-        if not int(g[f"{sid}_ok"]):
-            continue
-        assert not (out["status"][b] & 0x1), sid
-        _check_against(out, b, sid, g, int(g[f"{sid}_stable_row"]) if f"{sid}_stable_row" in g.files else 1 << 30)
-        checked += 1
-    assert checked >= 2
+        assert int(g[f"{sid}_ok"]) and not (out["status"][b] & 0x1), sid
+        rows = g[f"{sid}_rows"]
+        for key, tol in (("means", 1e-6), ("means_smoothed", 1e-6), ("covs", 1e-5), ("covs_smoothed", 1e-5)):
+            ref, got = g[f"{sid}_{key}"], out[key][b, rows]
+            if key.startswith("means"):
+                d = np.abs(got - ref)
+                d[:, 3] = np.abs((got[:, 3] - ref[:, 3] + 180.0) % 360.0 - 180.0)  # 359.9999 against 0.0001 is 2e-4 degrees
+                err = np.max(d / np.maximum(np.abs(ref), 1e-3), axis=1)
+            else:
+                err = np.max(np.abs(got - ref), axis=(-1, -2)) / np.max(np.abs(ref), axis=(-1, -2))
+            stable = g[f"{sid}_sens_{key}"] <= 1e-8
+            assert stable.mean() > 0.5, (sid, key)
+            assert err[stable].max() < tol, (sid, key, float(err[stable].max()))
+            assert err.max() < 1e-3, (sid, key, float(err.max()))
+            strict_rows += int(stable.sum()) if key == "means_smoothed" else 0
+    assert strict_rows > 1300  # of 1 545 sampled rows over the five ships
 
 
 @pytest.mark.gpu

@@ -115,3 +115,40 @@ def test_regime_vs_oracle(name, lanes):
     assert _cerrs(out["covs"][ok], P[ok]) < COV_TOL
     assert _errs(out["means_smoothed"][ok], sm[ok]) < MEAN_TOL
     assert _cerrs(out["covs_smoothed"][ok], sP[ok]) < COV_TOL
+
+
+def test_great_circle_steps_of_any_length_through_every_kernel_route():
+    """geodetic_dynamics (non_linear_process.py:46-85) for steps whose arc is anything from metres to several times round
+    the globe.  The kernels write the new latitude as lat + asin(sin(lat' - lat)), which holds only while the latitude
+    changes by less than 90 degrees; |sin(lat' - lat)| <= 1/2 alone does not say that (sin 150 = 1/2), so the fast route also
+    asks for cos(arc) > 0.  Found in round 4 by the reference-run fixture of ship WGAE (a filter state of -2 400 km/h over a
+    41-hour gap: the reference lands on 67.0 N, the unguarded identity on 33.1 S).  Checked here on the single-function
+    entry point and, through predict, on the lane, quad and literal routes."""
+    import ctypes as C
+
+    import torch
+    from oracle import ukf_oracle as orc
+    from track_estimators._hip import binding
+
+    lib = binding.require_gpu()
+    rng = np.random.default_rng(12)
+    n = 4096
+    x = np.stack([rng.uniform(-400, 400, n), rng.uniform(-89.9, 89.9, n), rng.uniform(-3000, 3000, n), rng.uniform(-720, 5000, n)])
+    dt = rng.choice([0.25, 1.0, 12.0, 41.5, 200.0], n)
+    x[:, 0] = [-18255.3776317, -83.04456611, -2367.84792821, 319.7269317]  # the WGAE state, dt 41.5
+    dt[0] = 41.5
+    sr, cr = rng.normal(0, 5, n), rng.normal(0, 100, n)
+    want = orc.geodetic_dynamics(x.T[:, None, :], dt[:, None], sr[:, None], cr[:, None])[:, 0, :].T
+    arcs = np.abs(x[2] * dt / 6378.137)
+    assert (arcs > np.pi / 2).sum() > 1000 and (arcs < 0.3).sum() > 200  # both routes are exercised
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    tx, tdt, tsr, tcr = dev(x), dev(dt), dev(sr), dev(cr)
+    out = torch.empty_like(tx)
+    binding.check(lib.ste_geodetic_dynamics_f64(n, tx.data_ptr(), tdt.data_ptr(), tsr.data_ptr(), tcr.data_ptr(),
+                                                out.data_ptr(), None), "geodetic")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert abs(got[1, 0] - want[1, 0]) < 1e-9 and abs(want[1, 0] - 66.9989) < 0.3  # the WGAE step: 67 N, not 33 S
+    np.testing.assert_allclose(got[1], want[1], rtol=0, atol=2e-10)  # latitudes, degrees
+    np.testing.assert_allclose(got[0], want[0], rtol=0, atol=2e-9)   # longitudes (|lon| up to 18 000 degrees)
+    np.testing.assert_allclose(got[2:], want[2:], rtol=1e-14, atol=1e-9)
