@@ -411,9 +411,12 @@ __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work,
         }
     }
     if (!good && lane == 0) *ok = 0;
-    // L row-major with 16-byte aligned rows for the broadcast reads of the substitution
+    // L row-major with 16-byte aligned rows for the broadcast reads of the substitution; S gets its copy now, so that the 64
+    // registers of a[] are free for x[] below (both live at once is 256 registers of arrays: accumulator-register shuffling)
 #pragma unroll
     for (int c = 0; c < T; c += 2) *reinterpret_cast<v2d*>(work + lane * LDB + c) = v2d{a[c], a[c + 1]};
+#pragma unroll
+    for (int c = 0; c < T; ++c) S[lane * LD + c] = (c <= lane) ? a[c] : 0.0;
     // lane c solves L x = e_c by forward substitution
     double x[T];
 #pragma unroll
@@ -429,10 +432,7 @@ __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work,
         x[r] = (acc0 + acc1) / work[r * LDB + r];
     }
 #pragma unroll
-    for (int c = 0; c < T; ++c) {
-        S[lane * LD + c] = (c <= lane) ? a[c] : 0.0;
-        X[c * LD + lane] = x[c];  // x[c] of lane `lane` = X[row c][column lane]
-    }
+    for (int c = 0; c < T; ++c) X[c * LD + lane] = x[c];  // x[c] of lane `lane` = X[row c][column lane]
 }
 
 __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
