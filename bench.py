@@ -740,29 +740,26 @@ def _main(stack):
                     "value": pool_result[1], "unit": "track-steps/s", "cores": pool_result[0],
                     "sample": f"{pool_result[0]} forked workers x {args.cpu_pool_tracks} tracks x {chb.Nmax} steps "
                               f"({pool_result[2]:.1f} s, slowest worker)"}
-        if world == 1 and not args.no_gp and args.cpu_tracks > 0:
-            # BASELINE.json configs[4], the second kernel set: not the headline metric, reported beside it so that the
-            # driver's default run measures it too (bench_gp.py alone prints the same object, with --fit for a whole fit)
-            import bench_gp
-
+        if world == 1 and args.cpu_tracks > 0:
+            # The other BASELINE configs, reported beside the headline so that the driver's default run measures them too.
             if pipe is not None:
                 pipe.close()  # its streams own hardware queues, and the fleet entry below builds a pipeline of its own
-            del dbs, db, pipe
+            dbs, db, pipe = [], None, None
             torch.cuda.empty_cache()
-            try:
-                out["extra"] = {"gp_config4": bench_gp.measure(1000, 2000, evals=3, cpu_evals=1)}
-            except Exception as exc:  # the headline line must not depend on the second workload
-                out["extra"] = {"gp_config4": {"error": f"{type(exc).__name__}: {exc}"}}
+            out["extra"] = {}
+            if not args.no_gp:
+                # configs[4], the second kernel set (bench_gp.py alone prints the same object, with --fit for a whole fit)
+                import bench_gp
+
+                try:
+                    out["extra"]["gp_config4"] = bench_gp.measure(1000, 2000, evals=3, cpu_evals=1)
+                except Exception as exc:  # the headline line must not depend on the second workload
+                    out["extra"]["gp_config4"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:
                 out["extra"]["config3_modern_ships_robust"] = measure_config3(dev)
             except Exception as exc:
                 out["extra"]["config3_modern_ships_robust"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_fleet and args.cpu_tracks > 0:
-            try:
-                if pipe is not None:
-                    pipe.close()
-            except NameError:
-                pass
             dbs, db, pipe = [], None, None
             torch.cuda.empty_cache()
             try:

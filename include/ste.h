@@ -85,8 +85,11 @@ typedef struct ste_ukf_batch_f64 {
     int32_t Tmax;  /* padded number of observations (columns of ShipTrack.z) */
     int32_t n;     /* state dimension, must be 4 */
     uint32_t flags;
-    int32_t tuning; /* 0 = defaults.  Tests: bit 8 = every smoother gain by the eigenvalue route (default: only where P_b is
-                       close to singular); other bits are ignored */
+    int32_t tuning; /* 0 = defaults.  Bit 8 (0x100): every smoother gain by the eigenvalue route (default: only where P_b is close
+                       to singular).  Bits 9 / 10 (0x200 / 0x400): ste_urtss_backward_f64 in its two-kernel / one-kernel form
+                       whatever the batch size (default: two kernels -- all gains at once, then a lean recurrence -- up to 4 096
+                       tracks, where the smoother is a few waves running a latency chain; one kernel above; same bits either way).
+                       Must not change between the backward calls made on one forward result.  Other bits are ignored */
 
     /* sigma-fan constants, computed by the host exactly as unscented.py:95,125,132 does (HOST values) */
     double fan_scale; /* n / (1 - W0) */
@@ -135,7 +138,8 @@ typedef struct ste_ukf_batch_f64 {
      * noise); columns 2-3 of D only at and after a track's first clamped / unconverged square root (elsewhere they are
      * 2 wi fan_scale times columns 2-3 of the filtered covariance); the last B words hold that step index per track.
      * ste_urtss_backward_f64 on the same batch then forms the gains K = D pinv(P_b) (:333) and runs the recurrence
-     * (:337-349); it only reads the workspace, so it may be called again on the same forward result.  Results are those
+     * (:337-349); it may be called again on the same forward result (the one-kernel form only reads the workspace; the
+     * two-kernel form of small batches rewrites rows into gains once and marks the workspace as such).  Results are those
      * of the stand-alone smoother to rounding.  Smoother rates of its own (sog_rate_rts / cog_rate_rts) are no obstacle:
      * speed and heading pass through the process model as x + rate * dt, so they move x_b[2:4] -- and through it P_b,
      * which is taken about the filtered mean -- by a known amount and leave D alone.

@@ -36,7 +36,7 @@ struct KParams {
     int B, Nmax, Tmax;
     unsigned flags;
     int tuning;
-    int fast_upd;  // H = diag(1, 1, 0, 0), R confined to the same block, no robust rescaling: closed-form update
+    int fast_upd;  // H = diag(1, 1, 0, 0), R confined to the same block: closed-form update (and closed-form robust rescaling)
     Mats m;
     const int32_t* nsteps;
     const double* x0;
@@ -723,19 +723,22 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
 
 // Measurement update on packed (x, P): the closed form for H = diag(1, 1, 0, 0) (kFastUpd, chosen by launch_forward from
 // the matrices), otherwise the general 4x4 route (any H, R; the opt-in robust rescaling).
-template <bool kFastUpd>
+template <bool kFastUpd, bool kRobust = false>
 __device__ __forceinline__ int lane_update(const Mats& p, double (&x)[4], double (&P)[10], const double (&zin)[4],
                                            const double* noise, size_t nrow, size_t B, size_t t) {
     if (kFastUpd) {
         double z[4];
         STE_UNROLL
         for (int c = 0; c < 4; ++c) z[c] = zin[c];
+        double r00 = p.R[0], r01 = p.R[1], r11 = p.R[5];
+        int st = 0;
+        if (kRobust) st = robust_rescale_sel2(p, x, P, z, r00, r01, r11);  // on the un-noised observation (unscented.py:228)
         if (noise) {
             STE_UNROLL
             for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
         }
-        lane_update_sel2(p.R[0], p.R[1], p.R[5], x, P, z);
-        return 0;
+        lane_update_sel2(r00, r01, r11, x, P, z);
+        return st;
     } else {
         double Pf[4][4];
         STE_UNROLL
@@ -765,7 +768,10 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
 // passes that the dispatcher doubles up on some SIMDs leave others empty.  The kernel holds 254 registers (its state,
 // plus the sin / cos coefficients and Q kept in VGPRs) and amdgpu_waves_per_eu(1, 1) pads the allocation to 264: a second
 // forward wave never fits on a SIMD, a smoother wave (234, allocation 240) does (264 + 240 <= 512).
-template <bool kGains, bool kFastUpd>
+// kRobust: the closed-form update with the closed-form robust rescaling in front of it (a template parameter, so that the
+// default instantiation's step loop is exactly the one measured without it); with kFastUpd false the general route reads
+// robust_iters itself.
+template <bool kGains, bool kFastUpd, bool kRobust = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
     const size_t B = (size_t)p.ld;  // row pitch of every per-track array (= the batch's own width unless it is a window)
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
-        st |= lane_update<kFastUpd>(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+        st |= lane_update<kFastUpd, kRobust>(p.m, x, P, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
 
     // The eigenvectors of the fan matrix carry over from step to step (warm start); restarted from the identity every
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool warm = (k & (kColdEvery - 1)) != 0;
             st |= lane_predict<kGains>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
                                        upd || noise_mode, noise_mode, flagged, first_bad, tk, Qv);
-            if (upd) st |= lane_update<kFastUpd>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (upd) st |= lane_update<kFastUpd, kRobust>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_hist(p, (size_t)k + 1, B, t, x, P);
         }
@@ -1105,7 +1111,86 @@ __device__ __forceinline__ int quad_update(const Mats& p, const QuadCtx& cx, dou
     return st;
 }
 
-template <bool kGains, bool kRobust>
+// The same update for H = diag(1, 1, 0, 0) and an R confined to that block (every example and the CLI of the reference), in
+// closed form like lane_update_sel2: S = H P H^T + R is 2 x 2, K = P[:, 0:2] S^+ has two columns, and the Joseph form needs the
+// products with those two columns only.  Row q of every matrix in lane q; rows 0 and 1 of P and the two columns of K reach
+// the other lanes by quad broadcasts.  ~150 instead of ~600 instructions per update; with kRobust the rescaling loop in closed
+// form too (robust_rescale_sel2 on the three entries of the block, the same on every lane of the quad).
+template <bool kRobust>
+__device__ __forceinline__ int quad_update_sel2(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
+                                                const double (&zin)[4], const double* noise, size_t nrow, size_t B,
+                                                size_t t) {
+#pragma clang fp contract(off)  // explicit fma() only
+    const int q = cx.q;
+    double z[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) z[c] = zin[c];
+    double Pn[4];  // row q of P, natural order
+    xorperm(Px, q, Pn);
+    const double p00 = bcast<0>(Pn[0]), p11 = bcast<1>(Pn[1]);
+    const double p01 = 0.5 * (bcast<0>(Pn[1]) + bcast<1>(Pn[0]));  // the quad keeps both triangles: symmetrised like quad_sym_pinv
+    double r00 = p.R[0], r01 = p.R[1], r11 = p.R[5];
+    int st = 0;
+    if (kRobust) {
+        double Pblk[10];
+        STE_UNROLL
+        for (int e = 0; e < 10; ++e) Pblk[e] = 0.0;
+        Pblk[tix(0, 0)] = p00;
+        Pblk[tix(0, 1)] = p01;
+        Pblk[tix(1, 1)] = p11;
+        st = robust_rescale_sel2(p, x, Pblk, z, r00, r01, r11);  // on the un-noised observation (unscented.py:228)
+    }
+    if (noise) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) z[c] += noise[(nrow * 4 + c) * B + t];
+    }
+    double Sm[4][4], Si[4][4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) Sm[r][c] = 0.0;
+    }
+    Sm[0][0] = p00 + r00;
+    Sm[0][1] = p01 + r01;
+    Sm[1][0] = Sm[0][1];
+    Sm[1][1] = p11 + r11;
+    sym_pinv4_block2(Sm, Si);
+    const double i00 = Si[0][0], i01 = Si[0][1], i11 = Si[1][1];
+    const double k0 = fma(Pn[1], i01, Pn[0] * i00), k1 = fma(Pn[1], i11, Pn[0] * i01);  // K[q][0], K[q][1]
+    const double y0 = z[0] - x[0], y1 = z[1] - x[1];
+    const double poison = fma(0.0, z[2], 0.0 * z[3]);  // K[:, 2:4] y[2:4] with K[:, 2:4] = 0: NaN iff z[2] or z[3] is not finite
+    const double xq = fma(k1, y1, fma(k0, y0, sel4(x, q))) + poison;
+    x[0] = bcast<0>(xq);
+    x[1] = bcast<1>(xq);
+    x[2] = bcast<2>(xq);
+    x[3] = floored_mod(bcast<3>(xq), 360.0);
+    // AP = (I - K H) P, row q:  P[q][c] - K[q][0] P[0][c] - K[q][1] P[1][c]
+    double AP[4], K0c[4], K1c[4], Pnew[4];
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        AP[c] = fma(-k1, bcast<1>(Pn[c]), fma(-k0, bcast<0>(Pn[c]), Pn[c]));
+    }
+    K0c[0] = bcast<0>(k0);
+    K0c[1] = bcast<1>(k0);
+    K0c[2] = bcast<2>(k0);
+    K0c[3] = bcast<3>(k0);
+    K1c[0] = bcast<0>(k1);
+    K1c[1] = bcast<1>(k1);
+    K1c[2] = bcast<2>(k1);
+    K1c[3] = bcast<3>(k1);
+    const double kr0 = fma(k1, r01, k0 * r00), kr1 = fma(k1, r11, k0 * r01);  // (K R)[q][0:2]
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        const double p1 = fma(-AP[1], K1c[c], fma(-AP[0], K0c[c], AP[c]));  // (A P A^T)[q][c]
+        const double p2 = fma(kr1, K1c[c], kr0 * K0c[c]);                    // (K R K^T)[q][c]
+        Pnew[c] = p1 + p2;
+    }
+    xorperm(Pnew, q, Px);
+    return st;
+}
+
+// kSel: H = diag(1, 1, 0, 0) with R in the same block (chosen by launch_forward from the matrices): closed-form update.
+template <bool kGains, bool kRobust, bool kSel>
 // __launch_bounds__(64, 2): at most 256 VGPRs, so that two waves fit on a SIMD.  What no longer fits is needed only by the
 // branching fallback of the propagation (its library-call constants go to scratch); the step loop itself has no scratch
 // access.  Alone the kernel is 5 % faster than the 362-VGPR build (no AGPR traffic), and two forward passes on the same
@@ -1170,7 +1255,8 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     if (initial_update) {
         double z0[4];
         load_vec(p.z, 0, B, t, z0);
-        st |= quad_update<kRobust>(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
+        st |= kSel ? quad_update_sel2<kRobust>(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t)
+                   : quad_update<kRobust>(p.m, cx, x, Px, z0, p.noise_upd, 0, B, t);  // kalman_filter.py:81
     }
     QuadBasis basis;
     basis.valid = false;
@@ -1204,7 +1290,9 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t,
                                (ui >= 0 && ui_ok) || noise_mode, noise_mode, flagged, first_bad);
-            if (ui >= 0 && ui_ok) st |= quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
+            if (ui >= 0 && ui_ok)
+                st |= kSel ? quad_update_sel2<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t)
+                           : quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_row((size_t)k + 1);
         }
@@ -1402,6 +1490,104 @@ __device__ __forceinline__ void load_recur_row(const KParams& p, size_t k, size_
     load_cov_p(p.fwd_cov, (p.flags & STE_FLAG_PACKED_COV) != 0, k, B, t, g.Pk);
 }
 
+// What the smoother's step k needs besides the recurrence itself: x_b, P_b (stored, or rebuilt from history rows k and
+// k + 1) and the gain K = D pinv(P_b) (unscented.py:315-333).  `cur` = work-row / history data of step k, (xn, Pn) = filtered
+// row k + 1, `full` = work row k holds x_b and P_b.  Shared by the one-kernel smoother (urtss_recur_l1) and the two-kernel
+// form for small batches (urtss_gains_all + urtss_recur_lean): same code, same bits.
+template <bool kShift>
+__device__ __forceinline__ int smoother_step_gain(const KParams& p, int k, size_t B, size_t t, const RecurRow& cur,
+                                                  const double (&xn)[4], const double (&Pn)[10], bool full, bool always_full,
+                                                  bool all_eig, double kappa, double first_bad, double (&xb)[4],
+                                                  double (&Pb)[10], double (&K)[4][4]) {
+    // x_b, P_b: stored (a quarter of the steps of the bench batch: loaded here, not a row ahead, to keep the
+    // registers of a whole row free), or the prediction itself -- the step was not followed by an update, so row
+    // k + 1 of the filtered history is x^-, P^-, and P_b = P^- + b b^T with b = x^- - x_k
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) xb[c] = xn[c];
+    if (kShift) {  // the smoother's own rates (load_recur_row)
+        xb[2] += cur.shift[0];
+        xb[3] += cur.shift[1];
+    }
+    {
+        double bv[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = r; c < 4; ++c) Pb[tix(r, c)] = fma(bv[r], bv[c], Pn[tix(r, c)]);
+        }
+    }
+    if (full) {
+        const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) xb[c] = w[(kWorkXb + c) * B];
+        STE_UNROLL
+        for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
+        if (kShift) {
+            // stored with the forward rates: P_b = C + b b^T with b = (weighted mean of the fan) - x_k, i.e. x_b - x_k
+            // less the recorded noise that was added to x_b (unscented.py:319-325); now b' = b + s, s = (0, 0, shift):
+            // P_b' = P_b + b s^T + s b^T + s s^T
+            double bv[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+            if (p.noise_rts) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) bv[c] -= p.noise_rts[((size_t)k * 4 + c) * B + t];
+            }
+            const double s2 = cur.shift[0], s3 = cur.shift[1];
+            Pb[tix(0, 2)] = fma(bv[0], s2, Pb[tix(0, 2)]);
+            Pb[tix(1, 2)] = fma(bv[1], s2, Pb[tix(1, 2)]);
+            Pb[tix(0, 3)] = fma(bv[0], s3, Pb[tix(0, 3)]);
+            Pb[tix(1, 3)] = fma(bv[1], s3, Pb[tix(1, 3)]);
+            Pb[tix(2, 2)] = fma(bv[2] + bv[2] + s2, s2, Pb[tix(2, 2)]);
+            Pb[tix(3, 3)] = fma(bv[3] + bv[3] + s3, s3, Pb[tix(3, 3)]);
+            Pb[tix(2, 3)] = fma(bv[2], s3, fma(s2, bv[3] + s3, Pb[tix(2, 3)]));
+            xb[2] += s2;
+            xb[3] += s3;
+        }
+    }
+    // the gain K = D pinv(P_b) (unscented.py:333)
+    double D[4][4];
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        D[r][0] = cur.D2[r * 2 + 0];
+        D[r][1] = cur.D2[r * 2 + 1];
+        D[r][2] = kappa * cur.Pk[tix(r, 2)];
+        D[r][3] = kappa * cur.Pk[tix(r, 3)];
+    }
+    if (!always_full) {
+        // rows 2-3 of D's first two columns are the cross moments of (speed, heading) with (lon, lat) about the
+        // predicted mean, i.e. the corresponding entries of P^- before Q was added.  Where the step was not followed
+        // by an update P^- is row k + 1 of the filtered history itself; on a full row (x_b, P_b stored) it is
+        // P_b - b b^T with b = x_b - x_k (no recorded noise here): D[2:4, 0:2] = (P^- - Q)[0:2, 2:4]^T.  (Forming
+        // P_b = P^- + b b^T first and subtracting b b^T again on every row cost ~eps |b_c b_r| on small cross moments.)
+        double bv[4];
+        STE_UNROLL
+        for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
+        STE_UNROLL
+        for (int r = 2; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                const double pm = full ? fma(-bv[c], bv[r], Pb[tix(c, r)]) : Pn[tix(c, r)];
+                D[r][c] = pm - p.m.Q[c * 4 + r];
+            }
+        }
+    }
+    if (__builtin_expect(__any((double)k >= first_bad), 0)) {
+        if ((double)k >= first_bad) {
+            const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                D[r][2] = w[(kWorkD23 + r * 2 + 0) * B];
+                D[r][3] = w[(kWorkD23 + r * 2 + 1) * B];
+            }
+        }
+    }
+    return smoother_gain(Pb, D, all_eig, K);
+
+}
+
 // kShift: the smoother has rates of its own (sog_rate_rts / cog_rate_rts); compiled out for batches that share them.
 template <bool kShift>
 __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
@@ -1443,93 +1629,8 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
         if (k < ns) {
             const RecurRow cur = nxt;
             const bool full = work_row_full(p, k, ui_n, always_full);
-            // x_b, P_b: stored (a quarter of the steps of the bench batch: loaded here, not a row ahead, to keep the
-            // registers of a whole row free), or the prediction itself -- the step was not followed by an update, so row
-            // k + 1 of the filtered history is x^-, P^-, and P_b = P^- + b b^T with b = x^- - x_k
-            double xb[4], Pb[10];
-            STE_UNROLL
-            for (int c = 0; c < 4; ++c) xb[c] = xn[c];
-            if (kShift) {  // the smoother's own rates (load_recur_row)
-                xb[2] += cur.shift[0];
-                xb[3] += cur.shift[1];
-            }
-            {
-                double bv[4];
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
-                STE_UNROLL
-                for (int r = 0; r < 4; ++r) {
-                    STE_UNROLL
-                    for (int c = r; c < 4; ++c) Pb[tix(r, c)] = fma(bv[r], bv[c], Pn[tix(r, c)]);
-                }
-            }
-            if (full) {
-                const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) xb[c] = w[(kWorkXb + c) * B];
-                STE_UNROLL
-                for (int e = 0; e < 10; ++e) Pb[e] = w[(kWorkPb + e) * B];
-                if (kShift) {
-                    // stored with the forward rates: P_b = C + b b^T with b = (weighted mean of the fan) - x_k, i.e. x_b - x_k
-                    // less the recorded noise that was added to x_b (unscented.py:319-325); now b' = b + s, s = (0, 0, shift):
-                    // P_b' = P_b + b s^T + s b^T + s s^T
-                    double bv[4];
-                    STE_UNROLL
-                    for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
-                    if (p.noise_rts) {
-                        STE_UNROLL
-                        for (int c = 0; c < 4; ++c) bv[c] -= p.noise_rts[((size_t)k * 4 + c) * B + t];
-                    }
-                    const double s2 = cur.shift[0], s3 = cur.shift[1];
-                    Pb[tix(0, 2)] = fma(bv[0], s2, Pb[tix(0, 2)]);
-                    Pb[tix(1, 2)] = fma(bv[1], s2, Pb[tix(1, 2)]);
-                    Pb[tix(0, 3)] = fma(bv[0], s3, Pb[tix(0, 3)]);
-                    Pb[tix(1, 3)] = fma(bv[1], s3, Pb[tix(1, 3)]);
-                    Pb[tix(2, 2)] = fma(bv[2] + bv[2] + s2, s2, Pb[tix(2, 2)]);
-                    Pb[tix(3, 3)] = fma(bv[3] + bv[3] + s3, s3, Pb[tix(3, 3)]);
-                    Pb[tix(2, 3)] = fma(bv[2], s3, fma(s2, bv[3] + s3, Pb[tix(2, 3)]));
-                    xb[2] += s2;
-                    xb[3] += s3;
-                }
-            }
-            // the gain K = D pinv(P_b) (unscented.py:333)
-            double D[4][4], K[4][4];
-            STE_UNROLL
-            for (int r = 0; r < 4; ++r) {
-                D[r][0] = cur.D2[r * 2 + 0];
-                D[r][1] = cur.D2[r * 2 + 1];
-                D[r][2] = kappa * cur.Pk[tix(r, 2)];
-                D[r][3] = kappa * cur.Pk[tix(r, 3)];
-            }
-            if (!always_full) {
-                // rows 2-3 of D's first two columns are the cross moments of (speed, heading) with (lon, lat) about the
-                // predicted mean, i.e. the corresponding entries of P^- before Q was added.  Where the step was not followed
-                // by an update P^- is row k + 1 of the filtered history itself; on a full row (x_b, P_b stored) it is
-                // P_b - b b^T with b = x_b - x_k (no recorded noise here): D[2:4, 0:2] = (P^- - Q)[0:2, 2:4]^T.  (Forming
-                // P_b = P^- + b b^T first and subtracting b b^T again on every row cost ~eps |b_c b_r| on small cross moments.)
-                double bv[4];
-                STE_UNROLL
-                for (int c = 0; c < 4; ++c) bv[c] = xb[c] - cur.xk[c];
-                STE_UNROLL
-                for (int r = 2; r < 4; ++r) {
-                    STE_UNROLL
-                    for (int c = 0; c < 2; ++c) {
-                        const double pm = full ? fma(-bv[c], bv[r], Pb[tix(c, r)]) : Pn[tix(c, r)];
-                        D[r][c] = pm - p.m.Q[c * 4 + r];
-                    }
-                }
-            }
-            if (__builtin_expect(__any((double)k >= first_bad), 0)) {
-                if ((double)k >= first_bad) {
-                    const double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
-                    STE_UNROLL
-                    for (int r = 0; r < 4; ++r) {
-                        D[r][2] = w[(kWorkD23 + r * 2 + 0) * B];
-                        D[r][3] = w[(kWorkD23 + r * 2 + 1) * B];
-                    }
-                }
-            }
-            st |= smoother_gain(Pb, D, all_eig, K);
+            double xb[4], Pb[10], K[4][4];
+            st |= smoother_step_gain<kShift>(p, k, B, t, cur, xn, Pn, full, always_full, all_eig, kappa, first_bad, xb, Pb, K);
             // the row of the next step: in flight during the recurrence arithmetic below (and across the loop edge)
             {
                 const int kn = clampk(k - 1);
@@ -1592,6 +1693,155 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     if (st) atomicOr(&p.status[t], st);
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same smoother in two kernels, for SMALL batches (a few waves: the real-data runs -- BASELINE configs[0] and [3], the
+// reference's 116-ship file).  There a wave of urtss_recur_l1 has a SIMD, indeed most of the chip, to itself, and its step
+// is a chain: the loads of x_b / P_b on full rows issued where they are needed, the gain solve (with the eigenvalue route out
+// of line for lanes whose P_b is close to singular), then the recurrence -- 4.7 us per step on configs[3].  But only the
+// recurrence  x^s_k = x_k + K_k (x^s_{k+1} - x_b),  P^s_k = P_k + K_k (P^s_{k+1} - P_b) K_k^T  is sequential; x_b, P_b and the
+// gain K_k = D_k pinv(P_b) depend on the forward pass alone (unscented.py:297-333).  So:
+//   urtss_gains_all   one lane per (step, track): x_b, P_b, K for every step of every track at once, written back into the
+//                     work row of that step (K over the D columns it was formed from, x_b and P_b into their slots on every row);
+//   urtss_recur_lean  one lane per track: loads K, x_b, P_b and the filtered row a step ahead, runs the recurrence.
+// Same device functions, same arithmetic, same bits as urtss_recur_l1.  The work rows hold K afterwards: the word that keeps
+// a track's first bad square root is stored negated (-(v) - 1) by the second kernel to say so, and a repeated
+// ste_urtss_backward_f64 on the same forward result skips the first kernel (the call stays repeatable).  Not for large
+// batches: 440 B more traffic per track-step, which a batch that fills the chip cannot afford (launch_backward).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLeanK01 = kWorkD, kLeanK23 = kWorkD23;  // K[r][0:2] at kLeanK01 + 2 r, K[r][2:4] at kLeanK23 + 2 r
+
+template <bool kShift>
+__global__ __launch_bounds__(64) void urtss_gains_all(const KParams p) {
+    const size_t B = (size_t)p.ld;
+    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (size_t)p.B * (size_t)p.Nmax) return;
+    const size_t t = g % (size_t)p.B;
+    const int k = (int)(g / (size_t)p.B);
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    if (k >= ns) return;
+    const double fb_raw = p.first_bad[t];
+    if (fb_raw < 0.0) return;  // the rows of this track already hold gains (a repeated backward call)
+    const bool always_full = p.noise_pred || p.noise_upd || p.noise_rts;
+    const bool all_eig = (p.tuning & 0x100) != 0;
+    const double kappa = (p.m.wi + p.m.wi) * p.m.fan_scale;
+    const bool packed = (p.flags & STE_FLAG_PACKED_COV) != 0;
+    RecurRow cur;
+    load_recur_row<kShift>(p, (size_t)k, B, t, always_full, cur);
+    double xn[4], Pn[10];
+    load_vec(p.fwd_mean, (size_t)k + 1, B, t, xn);
+    load_cov_p(p.fwd_cov, packed, (size_t)k + 1, B, t, Pn);
+    const bool full = work_row_full(p, k, p.upd_idx[(size_t)k * B + t], always_full);
+    double xb[4], Pb[10], K[4][4];
+    const int st = smoother_step_gain<kShift>(p, k, B, t, cur, xn, Pn, full, always_full, all_eig, kappa, fb_raw, xb, Pb, K);
+    double* w = p.rts_work + ((size_t)k * kWorkElems) * B + t;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        w[(kLeanK01 + 2 * r + 0) * B] = K[r][0];
+        w[(kLeanK01 + 2 * r + 1) * B] = K[r][1];
+        w[(kLeanK23 + 2 * r + 0) * B] = K[r][2];
+        w[(kLeanK23 + 2 * r + 1) * B] = K[r][3];
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) w[(kWorkXb + c) * B] = xb[c];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) w[(kWorkPb + e) * B] = Pb[e];
+    if (st) atomicOr(&p.status[t], st);
+}
+
+struct LeanRow {
+    double K[4][4], xb[4], Pb[10], xk[4], Pk[10];
+};
+__device__ __forceinline__ void load_lean_row(const KParams& p, size_t k, size_t B, size_t t, bool packed, LeanRow& g) {
+    const double* w = p.rts_work + (k * kWorkElems) * B + t;
+    STE_UNROLL
+    for (int r = 0; r < 4; ++r) {
+        g.K[r][0] = w[(kLeanK01 + 2 * r + 0) * B];
+        g.K[r][1] = w[(kLeanK01 + 2 * r + 1) * B];
+        g.K[r][2] = w[(kLeanK23 + 2 * r + 0) * B];
+        g.K[r][3] = w[(kLeanK23 + 2 * r + 1) * B];
+    }
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) g.xb[c] = w[(kWorkXb + c) * B];
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) g.Pb[e] = w[(kWorkPb + e) * B];
+    load_vec(p.fwd_mean, k, B, t, g.xk);
+    load_cov_p(p.fwd_cov, packed, k, B, t, g.Pk);
+}
+
+__global__ __launch_bounds__(64) void urtss_recur_lean(const KParams p) {
+    const size_t B = (size_t)p.ld;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (size_t)p.B) return;
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    const bool packed = (p.flags & STE_FLAG_PACKED_COV) != 0;
+    const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
+    {
+        const double fb = p.first_bad[t];
+        if (fb >= 0.0) p.first_bad[t] = -fb - 1.0;  // the work rows of this track hold gains from here on (see above)
+    }
+    double xs[4], Ps[10];
+    load_vec(p.fwd_mean, (size_t)ns, B, t, xs);
+    load_cov_p(p.fwd_cov, packed, (size_t)ns, B, t, Ps);
+    store_vec(p.sm_mean, (size_t)ns, B, t, xs);
+    store_cov_p(p.sm_cov, packed, (size_t)ns, B, t, Ps);
+    store_pos(p, (size_t)ns, B, t, xs);
+    LeanRow nxt;
+    if (ns > 0) load_lean_row(p, (size_t)(ns - 1), B, t, packed, nxt);
+    for (int k = p.Nmax - 1; k >= 0; --k) {
+        if (!__any(k < ns)) continue;
+        if (k < ns) {
+            const LeanRow cur = nxt;
+            load_lean_row(p, (size_t)min(max(k - 1, 0), last_row), B, t, packed, nxt);  // in flight during this step's arithmetic
+            double y[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) y[c] = xs[c] - cur.xb[c];
+            y[3] = wrap180(y[3]);
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                double acc = cur.xk[r];
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) acc = fma(cur.K[r][c], y[c], acc);
+                xs[r] = acc;
+            }
+            xs[3] = floored_mod(xs[3], 360.0);
+            double dP[10];
+            STE_UNROLL
+            for (int e = 0; e < 10; ++e) dP[e] = Ps[e] - cur.Pb[e];
+            double KdP[4][4];
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = 0; c < 4; ++c) {
+                    double acc = cur.K[r][0] * dP[tix(0, c)];
+                    STE_UNROLL
+                    for (int i = 1; i < 4; ++i) acc = fma(cur.K[r][i], dP[tix(i, c)], acc);
+                    KdP[r][c] = acc;
+                }
+            }
+            STE_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                STE_UNROLL
+                for (int c = r; c < 4; ++c) {
+                    double acc = KdP[r][0] * cur.K[c][0];
+                    STE_UNROLL
+                    for (int i = 1; i < 4; ++i) acc = fma(KdP[r][i], cur.K[c][i], acc);
+                    Ps[tix(r, c)] = cur.Pk[tix(r, c)] + acc;
+                }
+            }
+            store_vec(p.sm_mean, (size_t)k, B, t, xs);
+            store_cov_p(p.sm_cov, packed, (size_t)k, B, t, Ps);
+            store_pos(p, (size_t)k, B, t, xs);
+        }
+    }
+    double chk = 0.0;
+    STE_UNROLL
+    for (int c = 0; c < 4; ++c) chk += xs[c] * 0.0;
+    STE_UNROLL
+    for (int e = 0; e < 10; ++e) chk += Ps[e] * 0.0;
+    if (!(chk == 0.0)) atomicOr(&p.status[t], STE_STATUS_NAN);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // single-function kernels (fine-grained API parity: geodetic_dynamics, compute_sigma_points)
@@ -1807,7 +2057,7 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
     if (!(fabs(b->w0 + 8.0 * b->wi - 1.0) <= 1e-14))
         return fail(STE_EINVAL, "sigma weights must sum to one: w0 + 2 n wi = 1 (unscented.py:125-132)");
     {
-        bool sel = kp->m.robust_iters == 0;
+        bool sel = true;
         for (int r = 0; r < 4; ++r)
             for (int c = 0; c < 4; ++c) {
                 sel = sel && b->H[r * 4 + c] == ((r == c && r < 2) ? 1.0 : 0.0);
@@ -1888,21 +2138,23 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
     const bool robust = kp.m.robust_iters > 0;
     if (choose_lanes(kp.B, kp.flags) == 4) {
         const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
-        if (robust) {
-            if (kp.rts_work)
-                hipLaunchKernelGGL((ste::ukf_forward_q4<true, true>), dim3(gridq), dim3(64), 0, s, kp);
-            else
-                hipLaunchKernelGGL((ste::ukf_forward_q4<false, true>), dim3(gridq), dim3(64), 0, s, kp);
-        } else {
-            if (kp.rts_work)
-                hipLaunchKernelGGL((ste::ukf_forward_q4<true, false>), dim3(gridq), dim3(64), 0, s, kp);
-            else
-                hipLaunchKernelGGL((ste::ukf_forward_q4<false, false>), dim3(gridq), dim3(64), 0, s, kp);
+        const int which = (robust ? 4 : 0) | (kp.rts_work ? 2 : 0) | (kp.fast_upd ? 1 : 0);
+        switch (which) {
+#define STE_Q4(n, g, r, f) \
+    case n: hipLaunchKernelGGL((ste::ukf_forward_q4<g, r, f>), dim3(gridq), dim3(64), 0, s, kp); break;
+            STE_Q4(0, false, false, false) STE_Q4(1, false, false, true) STE_Q4(2, true, false, false) STE_Q4(3, true, false, true)
+            STE_Q4(4, false, true, false) STE_Q4(5, false, true, true) STE_Q4(6, true, true, false) STE_Q4(7, true, true, true)
+#undef STE_Q4
         }
         return check_hip(hipGetLastError(), "ukf_forward_q4 launch");
     }
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
-    if (kp.fast_upd) {
+    if (kp.fast_upd && robust) {
+        if (kp.rts_work)
+            hipLaunchKernelGGL((ste::ukf_forward_l1<true, true, true>), dim3(grid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL((ste::ukf_forward_l1<false, true, true>), dim3(grid), dim3(64), 0, s, kp);
+    } else if (kp.fast_upd) {
         if (kp.rts_work)
             hipLaunchKernelGGL((ste::ukf_forward_l1<true, true>), dim3(grid), dim3(64), 0, s, kp);
         else
@@ -1916,8 +2168,28 @@ int launch_forward(const ste::KParams& kp, hipStream_t s) {
     return check_hip(hipGetLastError(), "ukf_forward launch");
 }
 
+// Batches of at most this many tracks smooth with the two-kernel form (urtss_gains_all + urtss_recur_lean): up to there the
+// one-kernel smoother is a few waves running a latency chain of ~1.5-4.7 us per step, and the extra 440 B per track-step of
+// the gains pass cost less than the chain they remove; a batch that fills the chip is bound by bytes and issue instead.
+// tuning bit 9 (0x200) forces the two-kernel form, bit 10 (0x400) the one-kernel form (tests, measurements); the choice must
+// not change between the backward calls made on one forward result (the first two-kernel call turns the work rows into gains).
+constexpr int kLeanSmootherMaxTracks = 4096;
+
 int launch_backward(const ste::KParams& kp, hipStream_t s) {
     const unsigned grid = (unsigned)((kp.B + 63) / 64);
+    const bool shift = kp.sog_rate_rts || kp.cog_rate_rts;
+    if (kp.rts_work && kp.Nmax > 0 && ((kp.tuning & 0x200) || (!(kp.tuning & 0x400) && kp.B <= kLeanSmootherMaxTracks))) {
+        const size_t lanes = (size_t)kp.B * (size_t)kp.Nmax;
+        const unsigned ggrid = (unsigned)((lanes + 63) / 64);
+        if (shift)
+            hipLaunchKernelGGL(ste::urtss_gains_all<true>, dim3(ggrid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL(ste::urtss_gains_all<false>, dim3(ggrid), dim3(64), 0, s, kp);
+        int rc = check_hip(hipGetLastError(), "urtss_gains_all launch");
+        if (rc) return rc;
+        hipLaunchKernelGGL(ste::urtss_recur_lean, dim3(grid), dim3(64), 0, s, kp);
+        return check_hip(hipGetLastError(), "urtss_recur_lean launch");
+    }
     if (kp.rts_work) {
         if (kp.sog_rate_rts || kp.cog_rate_rts)
             hipLaunchKernelGGL(ste::urtss_recur_l1<true>, dim3(grid), dim3(64), 0, s, kp);

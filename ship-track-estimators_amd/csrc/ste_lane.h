@@ -423,6 +423,54 @@ __device__ __forceinline__ int quad_smoother_gain(const double (&Pb)[10], const 
     return st;
 }
 
+// Opt-in robustification (check_robustness, unscented.py:353-387) for the same H = diag(1, 1, 0, 0) / block-R case, in
+// closed form: S = H P H^T + R lives in the leading 2 x 2 block, so with y = z - x (the reference's innovation here, :420)
+//   gamma = |y^T S^+ y| = |y01^T Sb^+ y01|      criterion_index, :420-426
+//   denom = y^T S^+ R S^+ y = u^T Rb u, u = Sb^+ y01   update_lambda_factor, :468-478
+// and while gamma > chi_alpha: lambda += (gamma - chi_alpha) / denom, R <- lambda R (compounding, as written there).
+// Rescales (r00, r01, r11) in place; returns STE_STATUS_ROBUST_CAP when the criterion is still above chi_alpha after
+// robust_iters rescalings.  Branch-free per lane inside a wave-uniform loop: a lane that is done keeps its values.  The
+// unobserved components of y enter the reference's products through exact zeros of S^+ (0 * NaN = NaN): kept as a poison term.
+__device__ __forceinline__ int robust_rescale_sel2(const Mats& p, const double (&x)[4], const double (&P)[10],
+                                                    const double (&z)[4], double& r00, double& r01, double& r11) {
+#pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
+    const double y0 = z[0] - x[0], y1 = z[1] - x[1];
+    const double poison = fma(0.0, z[2] - x[2], 0.0 * (z[3] - x[3]));
+    auto terms = [&](double q00, double q01, double q11, double& gamma, double& denom) {
+        double Sm[4][4], Si[4][4];
+        STE_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) Sm[r][c] = 0.0;
+        }
+        Sm[0][0] = P[tix(0, 0)] + q00;
+        Sm[0][1] = P[tix(0, 1)] + q01;
+        Sm[1][0] = Sm[0][1];
+        Sm[1][1] = P[tix(1, 1)] + q11;
+        sym_pinv4_block2(Sm, Si);
+        const double u0 = fma(Si[0][1], y1, Si[0][0] * y0) + poison, u1 = fma(Si[1][1], y1, Si[0][1] * y0) + poison;
+        gamma = fabs(fma(y1, u1, y0 * u0));
+        const double v0 = fma(q01, u1, q00 * u0), v1 = fma(q11, u1, q01 * u0);
+        denom = fma(u1, v1, u0 * v0);
+    };
+    double gamma, denom, lambda = 1.0;
+    terms(r00, r01, r11, gamma, denom);
+    for (int it = 0; it < p.robust_iters; ++it) {
+        const bool active = gamma > p.chi_alpha;
+        if (!__any(active)) break;
+        const double l2 = lambda + (gamma - p.chi_alpha) / denom;
+        lambda = active ? l2 : lambda;
+        r00 = active ? r00 * lambda : r00;
+        r01 = active ? r01 * lambda : r01;
+        r11 = active ? r11 * lambda : r11;
+        double g2, d2;
+        terms(r00, r01, r11, g2, d2);
+        gamma = active ? g2 : gamma;
+        denom = active ? d2 : denom;
+    }
+    return gamma > p.chi_alpha ? STE_STATUS_ROBUST_CAP : 0;
+}
+
 // Measurement update for H = diag(1, 1, 0, 0) and an R that is zero outside its leading 2 x 2 block (unscented.py:219-265
 // with the matrices every example and the CLI of the reference use): S = H P H^T + R lives in that block, its
 // pseudo-inverse is sym_pinv4_block2's single rotation, K = P H^T S^+ has two columns, and the Joseph form

@@ -172,6 +172,9 @@ STATUS_HOST_INDEX = binding.STE_STATUS_HOST_INDEX  # the reference would raise I
 # Lane mapping used by batches that do not name one (HostBatch.lanes is None): 0 = the library picks by batch size.
 # A per-call flag of the C ABI underneath (STE_FLAG_LANES_1 / _4); the tests set this to run every case in both mappings.
 default_lanes = 0
+# ste_ukf_batch_f64.tuning of batches that do not name one (DeviceBatch(tuning=0)).  Bits (include/ste.h): 0x100 every smoother
+# gain by the eigenvalue route, 0x200 / 0x400 the two-kernel / one-kernel smoother whatever the batch size.  Tests set it.
+default_tuning = 0
 
 
 def pack_tracks(tracks: Sequence, dts_per_track: Sequence, x0s: Sequence, H, Q, R, P0, t0s=None,
@@ -380,7 +383,7 @@ class DeviceBatch:
             0 if hb.initial_update else binding.STE_FLAG_NO_INITIAL_UPDATE) | (
             binding.STE_FLAG_ROBUST if hb.robust else 0) | {0: 0, 1: binding.STE_FLAG_LANES_1, 4: binding.STE_FLAG_LANES_4}[lanes] | (
             binding.STE_FLAG_PACKED_COV if self.packed_cov else 0)
-        s.tuning = int(tuning)
+        s.tuning = int(tuning) if tuning else int(default_tuning)
         s.chi_alpha, s.robust_max_iter = float(hb.chi_alpha), 50
         s.fan_scale, s.w0, s.wi = fan_scale, w0, wi
         s.H, s.Q, s.R = hb.H.ctypes.data, hb.Q.ctypes.data, hb.R.ctypes.data

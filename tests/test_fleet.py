@@ -66,7 +66,7 @@ def test_run_fleet_is_run_batch_bit_for_bit_on_35000_distinct_tracks():
     assert np.array_equal(part["means_smoothed"], want["means_smoothed"])
 
 
-def _ragged(B=150, seed=3):
+def _ragged(B=150, seed=3, substeps=4):
     """Tracks of 5 .. 60 observations with irregular gaps (ragged, length-bucketed by pack_tracks)."""
     rng = np.random.default_rng(seed)
     H, Q, R, P0 = synthetic.example_matrices()
@@ -76,7 +76,7 @@ def _ragged(B=150, seed=3):
         sb = synthetic.make_batch(1, nobs=nobs, gap_h=float(rng.choice([0.5, 1.0, 2.0])), seed0=9000 + b)
         st = _Track(sb)
         tracks.append(st)
-        dts.append(np.repeat(st.dts / 4, 4))
+        dts.append(np.repeat(st.dts / substeps, substeps))
         x0s.append(st.z[:, 0])
     return batch.pack_tracks(tracks, dts, x0s, H, Q, R, P0)
 
@@ -234,3 +234,49 @@ def test_pipeline_orders_itself_behind_work_issued_outside_it():
             pipe.synchronize()
             side.synchronize()
             assert torch.equal(snap, ref.sm_mean) and torch.equal(db.sm_mean, ref.sm_mean)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "ragged-real-rates", "noise", "clamped-prior-all-eig"])
+def test_two_kernel_smoother_is_the_one_kernel_smoother_bit_for_bit(kind):
+    """Small batches smooth in two kernels -- x_b, P_b and the gain K = D pinv(P_b) of EVERY step at once (they depend on the
+    forward pass alone, unscented.py:297-333), then a recurrence that only loads them -- because a few waves of the one-kernel
+    smoother are a latency chain (include/ste.h ``tuning`` bits 9 / 10, csrc/ste_kernels.hip launch_backward).  Same device
+    functions, same bits: histories, sm_pos, status; and the call stays repeatable although the work rows hold gains
+    afterwards."""
+    import torch
+
+    tun = 0
+    if kind == "uniform":
+        _, hb = _uniform(300, 31, nobs=40, substeps=4)
+    elif kind == "ragged-real-rates":
+        # thirds of the gaps: most float-equality triggers miss (kalman_filter.py:98-101), so the smoother's rate indexing
+        # (unscented.py:287-292) differs from the forward pass's -> sog_rate_rts, the kShift kernels
+        hb = _ragged(B=90, seed=8, substeps=3)
+        assert hb.sog_rate_rts is not None
+    elif kind == "noise":
+        _, hb = _uniform(130, 5, nobs=30, substeps=2)
+        rng = np.random.default_rng(1)
+        hb.noise_pred = 1e-3 * rng.standard_normal((hb.Nmax, 4, hb.B))
+        hb.noise_upd = 1e-3 * rng.standard_normal((hb.Nmax + 1, 4, hb.B))
+        hb.noise_rts = 1e-3 * rng.standard_normal((hb.Nmax, 4, hb.B))
+    else:
+        _, hb = _uniform(70, 9, nobs=30, substeps=4)
+        P0 = np.repeat(np.eye(4)[None], hb.B, 0)
+        P0[3] = np.diag([1.0, -0.3, 1.0, 1.0])
+        hb.P0 = np.ascontiguousarray(P0.reshape(hb.B, 16).T)
+        tun = 0x100
+    outs = {}
+    for form in (0x400, 0x200):
+        db = batch.DeviceBatch(hb, tuning=tun | form, sm_pos=True)
+        _zero_outputs(db)
+        db.run()
+        torch.cuda.synchronize()
+        outs[form] = [t.clone() for t in (db.sm_mean, db.sm_cov, db.sm_pos, db.status, db.fwd_mean)]
+        if form == 0x200:
+            db.sm_mean.zero_()
+            db.backward()  # again, on work rows that now hold gains
+            torch.cuda.synchronize()
+            assert torch.equal(db.sm_mean, outs[form][0])
+            assert bool((db.rts_work[-1] < 0).all())  # the marker: first-bad word stored negated
+    for a, b in zip(outs[0x400], outs[0x200]):
+        assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))

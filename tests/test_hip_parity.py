@@ -28,6 +28,18 @@ def lanes_per_track(request):
     batch.default_lanes = prev
 
 
+@pytest.fixture(params=[0, 0x400], ids=["smoother-by-size", "one-kernel-smoother"], autouse=True)
+def smoother_form(request):
+    """The goldens are small batches, which smooth in the two-kernel form by default (all gains at once, then the lean
+    recurrence: include/ste.h ``tuning``); every parity test also runs with the one-kernel smoother the bench batch uses."""
+    from track_estimators import batch
+
+    prev = batch.default_tuning
+    batch.default_tuning = request.param
+    yield request.param
+    batch.default_tuning = prev
+
+
 CASES = [("ukf_synthetic.npz", i) for i in range(10)] + [("ukf_edge.npz", i) for i in range(3)] + [
     ("ukf_ship_01203823.npz", i) for i in range(2)
 ]

@@ -24,7 +24,7 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
             seen.add(key)
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 names = sorted({n for k in acc for n in acc[k]})
-if not acc or not all(k in acc for _, k in [("f", "ste::ukf_forward_l1<true, true>")]):
+if not acc or not all(k in acc for _, k in [("f", "ste::ukf_forward_l1<true, true, false>")]):
     sys.exit(f"no counter files of the filter kernels under {root}: nothing written")
 TS = 5.0e6
 with open(f"profiles/{RN}_pmc_counters_per_launch.csv", "w") as f:
@@ -36,8 +36,8 @@ with open(f"profiles/{RN}_pmc_counters_per_launch.csv", "w") as f:
     for k in sorted(acc):
         c = {n: sum(v) / len(v) for n, v in acc[k].items()}
         f.write('"%s",%d,%.3f,' % (k, len(dur[k]), sum(dur[k]) / len(dur[k])) + ",".join(("%.1f" % c[n]) if n in c else "" for n in names) + "\n")
-rows = [("ukf_forward", "ste::ukf_forward_l1<true, true>"), ("urtss_backward", "ste::urtss_recur_l1<false>"),
-        ("ukf_forward_q4", "ste::ukf_forward_q4<true, false>")]
+rows = [("ukf_forward", "ste::ukf_forward_l1<true, true, false>"), ("urtss_backward", "ste::urtss_recur_l1<false>"),
+        ("ukf_forward_q4", "ste::ukf_forward_q4<true, false, true>")]
 with open(f"profiles/{RN}_counters_per_track_step.csv", "w") as f:
     f.write("# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp   (kernels of round " + RN + ", 10 000 tracks x 500 steps\n")
     f.write("# = 5.0e6 track-steps per launch; one --pmc pass per counter group (profiles/tools/pmc_passes_" + RN + ".sh), averages over the launches of each kernel; raw\n")
