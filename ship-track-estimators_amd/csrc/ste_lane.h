@@ -114,7 +114,7 @@ __device__ __forceinline__ void dbg_sweep_probe(const double (&a)[10], int sweep
 // track's result does not depend on which tracks share its wave.
 __device__ __forceinline__ bool jacobi_sweeps_p(double (&a)[10], double (&V)[4][4]) {
     for (int sweep = 0; sweep <= kMaxSweeps; ++sweep) {
-#ifdef STE_DEBUG_SWEEPS  // scratch/dbg_sweeps3.py: how many sweeps a fan costs, and how many of their rotations any lane needed
+#ifdef STE_DEBUG_SWEEPS  // profiles/tools/jacobi_sweep_probe.py: how many sweeps a fan costs, and how many of their rotations any lane needed
         dbg_sweep_probe(a, sweep);
 #endif
         // The first two sweeps run unasked: measured on the bench batch, 99.6 % of the solves need at least two (a warm
