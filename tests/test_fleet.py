@@ -280,3 +280,19 @@ def test_two_kernel_smoother_is_the_one_kernel_smoother_bit_for_bit(kind):
             assert bool((db.rts_work[-1] < 0).all())  # the marker: first-bad word stored negated
     for a, b in zip(outs[0x400], outs[0x200]):
         assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))
+
+
+def test_run_fleet_forward_only_and_selected_outputs():
+    """``smooth=False`` (the filter alone, no smoother buffers) and ``outputs`` (bring back only what is asked for) through
+    windows, against the single launch."""
+    _, hb = _uniform(1000, 77_000, nobs=20, substeps=4)
+    hb.lanes = 1
+    want = batch.run_batch(hb, smooth=False)
+    got = batch.run_fleet(hb, chunk=256, smooth=False, outputs=("means",))
+    assert set(got) == {"means", "status", "nsteps", "device_batch"} and got["device_batch"].sm_mean is None
+    assert np.array_equal(got["means"], want["means"]) and np.array_equal(got["status"], want["status"])
+    both = batch.run_fleet(hb, chunk=256, outputs=("covs_smoothed", "means"))
+    full = batch.run_batch(hb)
+    assert np.array_equal(both["covs_smoothed"], full["covs_smoothed"]) and np.array_equal(both["means"], full["means"])
+    with pytest.raises(ValueError):
+        batch.run_fleet(got["device_batch"], chunk=256)  # built without smoothed outputs
