@@ -1,4 +1,6 @@
 // micro-benchmark 4: the panel_gemm_t loop in isolation, pieces switchable at compile time
+// -DTILEMAJOR (round 4): the operands laid out as contiguous 64 x 64 tiles (rows of a tile 512 B apart) instead of rows of
+// the whole matrix (16.5 KB apart): does the memory system deliver a wave-level load of 16 rows x 128 B faster then?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -6,14 +8,27 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define SHAREMASK 255  // 255: every workgroup streams its own rows; 0: all workgroups read the same, cache-resident rows
 #endif
 constexpr int T = 64, LDB = 66;
+#ifdef TILEMAJOR
+constexpr int TSTEP = 4096;  // doubles from one k-block of a panel to the next
+#else
+constexpr int TSTEP = 64;
+#endif
 struct RowFrag { v4d v[4]; };
 __device__ __forceinline__ void load_rows(RowFrag& f, const double* const (&pr)[4], int k) {
 #pragma unroll
+#ifdef TILEMAJOR  // k = 64 kb + 16 sub: tile kb of the panel, column 16 sub of it
+    for (int n = 0; n < 4; ++n) f.v[n] = *reinterpret_cast<const v4d*>(pr[n] + (size_t)(k >> 6) * 4096 + (k & 63));
+#else
     for (int n = 0; n < 4; ++n) f.v[n] = *reinterpret_cast<const v4d*>(pr[n] + k);
+#endif
 }
 __device__ __forceinline__ void stage_load(v4d (&st)[4], const double* src, size_t ld, int tid) {
 #pragma unroll
+#ifdef TILEMAJOR  // src names the tile: 64 rows of 64 doubles, contiguous
+    for (int q = 0; q < 4; ++q) { const int e = tid + 256 * q; st[q] = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * 64 + (e & 15) * 4); }
+#else
     for (int q = 0; q < 4; ++q) { const int e = tid + 256 * q; st[q] = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 4); }
+#endif
 }
 __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int tid) {
 #pragma unroll
@@ -38,12 +53,16 @@ __global__ __launch_bounds__(256) void k(const double* A, double* out, long long
     const double* base = A + (size_t)(blockIdx.x & SHAREMASK) * 5 * 64 * ld;   // 5 row panels of 64 rows per workgroup
     const double* shared = base;
     const double* own[4];
+#ifdef TILEMAJOR  // panel p of the workgroup = ld / 64 tiles of 4096 doubles
+    for (int n = 0; n < 4; ++n) own[n] = base + (size_t)(1 + wave) * 64 * ld + (size_t)(r + 16 * n) * 64 + 4 * g;
+#else
     for (int n = 0; n < 4; ++n) own[n] = base + (size_t)(64 * (1 + wave) + r + 16 * n) * ld + 4 * g;
+#endif
     v4d acc[4][4];
     for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0, 0, 0, 0};
     const int kb0 = 0, kb1 = nblk;
     v4d st[4];
-    stage_load(st, shared + (size_t)kb0 * T, ld, tid);
+    stage_load(st, shared + (size_t)kb0 * TSTEP, ld, tid);
     RowFrag f0, f1, f2, f3;
     load_rows(f0, own, kb0 * T); load_rows(f1, own, kb0 * T + 16); load_rows(f2, own, kb0 * T + 32); load_rows(f3, own, kb0 * T + 48);
     stage_store(stage, st, tid);
@@ -54,7 +73,7 @@ __global__ __launch_bounds__(256) void k(const double* A, double* out, long long
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
         const bool more = kb + 1 < kb1, live = kb >= wb0;
         const int kn = (more ? kb + 1 : kb0) * T;
-        stage_load(st, shared + (size_t)kn, ld, tid);
+        stage_load(st, shared + (size_t)(kn / T) * TSTEP, ld, tid);
         mma_sub(acc, cur, 0, f0, r, g, live); load_rows(f0, own, kn);
         mma_sub(acc, cur, 1, f1, r, g, live); load_rows(f1, own, kn + 16);
         mma_sub(acc, cur, 2, f2, r, g, live); load_rows(f2, own, kn + 32);
