@@ -720,13 +720,14 @@ class SmootherPipeline:
     def bwd_stream(self):
         return self.bwd_streams[0]
 
-    def submit(self, db: "DeviceBatch", after_smoother=None, timing=None, final: bool = False, smooth: bool = True):
+    def submit(self, db: "DeviceBatch", after_smoother=None, timing=None, final: bool = False, smooth: bool = True,
+               slices: Optional[int] = None):
         """Queue forward + smoother of ``db``; returns the event that marks its smoother (and ``after_smoother``) done.
 
         ``after_smoother(stream)``: optional callable run with the smoother stream current, right after the smoother
         kernels are queued (the multi-GPU driver starts its all-gather of the smoothed positions there).  It may return
         an event; the next use of ``db``'s buffers then waits for that event too (a collective still reading them).
-        ``smooth=False``: forward pass only.
+        ``smooth=False``: forward pass only.  ``slices``: time slices of this batch's forward pass (default: the pipeline's).
         ``timing``: optional list of four timing-enabled events, recorded before / after the forward kernel on its
         forward stream and before / after the smoother kernels on its smoother stream.
         ``final``: nothing follows this batch, so its smoother gets an unrestricted stream (the whole chip) instead of the
@@ -763,7 +764,7 @@ class SmootherPipeline:
         if self.forward_lanes and not (flags & (binding.STE_FLAG_LANES_1 | binding.STE_FLAG_LANES_4)):
             db.struct.flags = flags | (binding.STE_FLAG_LANES_1 if self.forward_lanes == 1 else binding.STE_FLAG_LANES_4)
         try:
-            db.forward(fwd_stream, slices=self.slices, mark=False)
+            db.forward(fwd_stream, slices=self.slices if slices is None else int(slices), mark=False)
         finally:
             db.struct.flags = flags
         ready = timing[1] if timing is not None else torch.cuda.Event()
