@@ -443,18 +443,31 @@ class DeviceBatch:
         return w
 
     def upload_tracks(self, lo: int, hi: int, stream=None):
-        """Bring tracks [lo, hi) of the host batch into the (``upload=False``) input tensors: page-locked staging and
-        asynchronous copies on ``stream``; returns the event that marks them resident."""
+        """Bring tracks [lo, hi) of the host batch into the (``upload=False``) input tensors: page-locked staging, filled by
+        a few threads (the strided slice copies release the GIL; one thread moves ~12 GB/s, and direct strided DMA from
+        page-locked NumPy memory was measured far slower: 0.3 GB/s), then asynchronous copies on ``stream``; returns the event
+        that marks them resident."""
         torch = self.torch
         stream = stream or torch.cuda.current_stream(self.device)
+        jobs = []
+        for name in self._IN:
+            ten = self.t[name]
+            if ten is None or (name == "P0" and self.hb.shared_p0):
+                continue
+            src = getattr(self.hb, name)[..., lo:hi]
+            stage = torch.empty(src.shape, dtype=ten.dtype, pin_memory=True)
+            jobs.append((ten, stage, src))
+
+        def fill(job):
+            job[1].numpy()[...] = job[2]
+
+        if sum(j[2].nbytes for j in jobs) > (64 << 20):
+            list(_staging_pool().map(fill, jobs))
+        else:
+            for j in jobs:
+                fill(j)
         with torch.cuda.stream(stream):
-            for name in self._IN:
-                ten = self.t[name]
-                if ten is None or (name == "P0" and self.hb.shared_p0):
-                    continue
-                src = getattr(self.hb, name)[..., lo:hi]
-                stage = torch.empty(src.shape, dtype=ten.dtype, pin_memory=True)
-                stage.numpy()[...] = src
+            for ten, stage, _ in jobs:
                 ten[..., lo:hi].copy_(stage, non_blocking=True)
             if self.hb.shared_p0 and lo == 0:
                 self.t["P0"].copy_(torch.from_numpy(np.ascontiguousarray(self.hb.P0)))
@@ -835,6 +848,18 @@ class SmootherPipeline:
 
 _live_pipelines = weakref.WeakSet()
 _atexit_registered = False
+_pool = None
+
+
+def _staging_pool():
+    """A few threads for the host-side staging copies of fleet uploads (NumPy slice copies release the GIL)."""
+    global _pool
+    if _pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)) // 2)), thread_name_prefix="ste-stage")
+    return _pool
 # Time slices per pipelined forward pass when SmootherPipeline is not told.  One: slices are bit-identical and let the waves
 # of the passes in flight re-balance at every boundary, but a stream's next slice waits for ALL waves of the one before, and
 # with every window advancing in step no smoother has anything to do until the end -- measured (10 000-track batches, 7 + 6
