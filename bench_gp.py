@@ -131,6 +131,21 @@ def measure(tracks=1000, nobs=2000, evals=3, cpu_evals=2, fit=False):
                      "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "flops_per_objective": float(n) ** 3},
     }
+    if (B, n) == (1000, 2000):
+        # HBM bytes of one batched objective from the committed rocprofv3 --pmc summary of this command (all kernels of the
+        # objective; FETCH_SIZE doubled per the gfx950 calibration, profiles/README.md)
+        path = os.path.join(ROOT, "profiles", "r04_gp_counters_1000x2000.csv")
+        try:
+            import csv
+
+            with open(path) as f:
+                rows = list(csv.DictReader(ln for ln in f if not ln.startswith("#")))
+            out["roofline"]["traffic"] = sum((float(r["hbm_read_GB"]) + float(r["hbm_write_GB"])) * 1e9 for r in rows)
+            out["roofline"]["traffic_unit"] = "bytes per batched objective (all kernels)"
+            out["roofline"]["traffic_source"] = os.path.relpath(path, ROOT)
+            out["roofline"]["kernels_ms"] = {r["kernel"].replace("stegp::", ""): float(r["avg_ms"]) for r in rows}
+        except (OSError, KeyError, ValueError):
+            pass
     if args.cpu_evals > 0:
         from oracle import gp_oracle as gpo
 
