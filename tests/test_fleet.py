@@ -296,3 +296,26 @@ def test_run_fleet_forward_only_and_selected_outputs():
     assert np.array_equal(both["covs_smoothed"], full["covs_smoothed"]) and np.array_equal(both["means"], full["means"])
     with pytest.raises(ValueError):
         batch.run_fleet(got["device_batch"], chunk=256)  # built without smoothed outputs
+
+
+def test_windows_offset_every_per_track_array():
+    """Windows of a fleet with per-track priors, recorded noise, the robust update and a ragged tail: every per-track pointer of
+    the batch struct has to move with the window (P0 [16][B], the three noise arrays, nsteps, status), not only the histories."""
+    _, hb = _uniform(700, 123, nobs=24, substeps=4)
+    hb.lanes = 1
+    rng = np.random.default_rng(2)
+    P0 = np.repeat(np.eye(4)[None], hb.B, 0) * rng.uniform(0.5, 2.0, (hb.B, 1, 1))
+    hb.P0 = np.ascontiguousarray(P0.reshape(hb.B, 16).T)
+    hb.noise_pred = 1e-3 * rng.standard_normal((hb.Nmax, 4, hb.B))
+    hb.noise_upd = 1e-3 * rng.standard_normal((hb.Nmax + 1, 4, hb.B))
+    hb.noise_rts = 1e-3 * rng.standard_normal((hb.Nmax, 4, hb.B))
+    hb.nsteps = hb.nsteps.copy()
+    hb.nsteps[rng.integers(0, hb.B, 60)] = rng.integers(0, hb.Nmax, 60)
+    hb.robust = True
+    want = batch.run_batch(hb)
+    got = batch.run_fleet(hb, chunk=192, slices=2)
+    for k in HIST:
+        for b in range(hb.B):
+            n1 = hb.nsteps[b] + 1
+            assert np.array_equal(got[k][b, :n1], want[k][b, :n1]), (k, b)
+    assert np.array_equal(got["status"], want["status"])
