@@ -19,6 +19,7 @@
 //   backward : unscented.py:285-351 (rts_step)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -60,6 +61,7 @@ struct KParams {
     int ld;            // tracks per row of every per-track array (ste.h: track_stride; = B for a batch of its own)
     int k0;            // forward pass, time slices: absolute index of this launch's step 0 (0 for a whole pass); every
                        // per-step pointer above already names row k0, Nmax is the slice's length (see slice_params)
+    int qpw;           // quad forward kernel: quads (tracks) per wave, 1 .. 16 (launch_forward: fewer when waves are scarce)
     double* first_bad; // [ld] the last row of rts_work (first bad square root per track), or nullptr
     double* sm_pos;    // [Nmax+1][2][ld] smoothed lon / lat beside sm_mean, or nullptr
 };
@@ -1197,9 +1199,14 @@ template <bool kGains, bool kRobust, bool kSel>
 // compute units take 3.5 ms together instead of 2 x 2.36: a lone wave leaves half of the fp64 pipe's issue slots unused.
 __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     const size_t B = (size_t)p.ld;  // row pitch of every per-track array
-    const size_t gl = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const size_t t = gl >> 2;
-    const int q = (int)(gl & 3);
+    // p.qpw quads per wave (16 fill it).  A wave pays for the slowest of its tracks at every step -- another Jacobi sweep, another
+    // robust rescaling, the device-library fallback of the fan whenever ANY of its lanes asks -- so when there are fewer tracks than
+    // the chip has SIMDs to spare, each gets a wave of its own (launch_forward): BASELINE configs[3]'s seven ships take 41 .. 89 ms
+    // each on their own and 128 ms sharing one wave.
+    const int quad = (int)(threadIdx.x >> 2);
+    if (quad >= p.qpw) return;
+    const size_t t = (size_t)blockIdx.x * (size_t)p.qpw + (size_t)quad;
+    const int q = (int)(threadIdx.x & 3);
     if (t >= (size_t)p.B) return;  // whole quads leave together
     const bool cont = (p.flags & kFlagContinue) != 0;  // a later time slice (see ukf_forward_l1; full covariances only)
     const int ns = (p.nsteps ? p.nsteps[t] - p.k0 : p.Nmax);
@@ -1999,6 +2006,7 @@ thread_local char g_err[512] = "";
 // (measured on MI355X).  STE_FLAG_LANES_1 / STE_FLAG_LANES_4 in the batch's flags override the choice for
 // that call.
 constexpr int kQuadMaxTracks = 32768;
+constexpr size_t kQuadSpreadWaves = 1024;  // SIMDs of an MI355X: up to this many tracks, one quad (track) per wave
 int choose_lanes(int B, unsigned flags) {
     if (flags & STE_FLAG_LANES_1) return 1;
     if (flags & STE_FLAG_LANES_4) return 4;
@@ -2090,6 +2098,7 @@ int make_params(const ste_ukf_batch_f64* b, bool need_fwd_in, bool need_sm_out, 
         return fail(STE_EINVAL, "track_stride must be 0 (= B) or in [B, 2^31): a window lies inside the rows of its fleet");
     kp->ld = b->track_stride ? (int)b->track_stride : b->B;
     kp->k0 = 0;
+    kp->qpw = 16;
     kp->first_bad = b->rts_work ? b->rts_work + (size_t)b->Nmax * STE_RTS_WORK_ROWS * (size_t)kp->ld : nullptr;
     kp->sm_pos = b->sm_pos;
     return STE_OK;
@@ -2137,11 +2146,15 @@ int slice_params(const ste_ukf_batch_f64* b, ste::KParams* kp) {
 int launch_forward(const ste::KParams& kp, hipStream_t s) {
     const bool robust = kp.m.robust_iters > 0;
     if (choose_lanes(kp.B, kp.flags) == 4) {
-        const unsigned gridq = (unsigned)(((size_t)kp.B * 4 + 63) / 64);
+        // quads per wave: 16 fill a wave; with fewer tracks than SIMDs to spare every track gets a wave (and a SIMD) of its own,
+        // so that no track waits for another's extra sweep, rescaling or slow-path fan (see ukf_forward_q4)
+        ste::KParams kq = kp;
+        kq.qpw = (int)std::min<size_t>(16, std::max<size_t>(1, ((size_t)kp.B + kQuadSpreadWaves - 1) / kQuadSpreadWaves));
+        const unsigned gridq = (unsigned)(((size_t)kp.B + kq.qpw - 1) / kq.qpw);
         const int which = (robust ? 4 : 0) | (kp.rts_work ? 2 : 0) | (kp.fast_upd ? 1 : 0);
         switch (which) {
 #define STE_Q4(n, g, r, f) \
-    case n: hipLaunchKernelGGL((ste::ukf_forward_q4<g, r, f>), dim3(gridq), dim3(64), 0, s, kp); break;
+    case n: hipLaunchKernelGGL((ste::ukf_forward_q4<g, r, f>), dim3(gridq), dim3(64), 0, s, kq); break;
             STE_Q4(0, false, false, false) STE_Q4(1, false, false, true) STE_Q4(2, true, false, false) STE_Q4(3, true, false, true)
             STE_Q4(4, false, true, false) STE_Q4(5, false, true, true) STE_Q4(6, true, true, false) STE_Q4(7, true, true, true)
 #undef STE_Q4
