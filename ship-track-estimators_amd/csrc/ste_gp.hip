@@ -10,8 +10,11 @@
 //   gp_potrf_cols  blocked left-looking Cholesky in column order, one workgroup per matrix, four tiles per pass
 //   gp_trtri_cols  U = L^-T (upper, row-major) in column order (large batches); gp_trtri_rows: one workgroup per
 //                  (matrix, block row) for small batches
-//   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised) -> gradient
-//   gp_w / gp_alpha / gp_quad / gp_finish   alpha = U (U^T y), log-marginal likelihood, gradient assembly
+//   gp_kinv_trace  K^-1 = U U^T tile by tile, reduced on the fly against dK/dtheta (never materialised), and
+//                  alpha^T (dK/dtheta) alpha with the same Krbf values -> gradient
+//   alpha = U (U^T y): in the column-ordered kernels the right-hand sides ride along (w = L^-1 y by forward substitution
+//                  in gp_potrf_cols, alpha = U w tile by tile in gp_trtri_cols); gp_w / gp_alpha for the row-ordered inverse
+//   gp_alpha / gp_finish   per-block shares of y.alpha, log det, alpha.alpha -> log-marginal likelihood, gradient assembly
 //   gp_kstar / gp_predict   posterior mean and variance at new times (variance as a tile GEMM against K^-1)
 //
 // All dense work is 64x64-tile "NT" products C += A_rows * B_rows^T with both operands row-major and contiguous along
@@ -32,6 +35,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int T = 64;  // tile edge
+constexpr int kMaxOut = 4;  // ste_gp_batch_f64.nout <= 4
 constexpr double kLog2Pi = 1.8378770664093453;
 
 struct GpParams {
@@ -381,6 +385,48 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// The right-hand sides ride along with the factorisation and the inversion (gp_potrf_cols: w = L^-1 y by forward
+// substitution, gp_trtri_cols: alpha = U w), in place in the alpha buffer.  Its 64-row blocks are read, modified and
+// written by different waves of the one workgroup that owns the matrix, in different columns: the accesses go to L2
+// (agent scope) so that no wave sees a line its CU cached before another wave's update.
+__device__ __forceinline__ double ld_l2(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_l2(double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A 64-vector parked in LDS in the order the transposed accumulators meet it: element 16 m + 4 e + g at (4 m + g) * 4 + e,
+// so that lane group g reads the four values of block row m as one 32-byte word.
+__device__ __forceinline__ int rhs_slot(int idx) { return (((idx >> 4) * 4 + (idx & 3)) * 4 + ((idx >> 2) & 3)); }
+// part[o][n] += sum_e row[n][e] * vec_o[16 m + 4 e + g]: one block row of a (tile x vector) product, tile in accumulator layout
+__device__ __forceinline__ void rhs_accumulate(double (&part)[4][4], const v4d (&row)[4], const double* vec, int m, int g,
+                                               int nout) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < nout) {
+            const v4d wv = *reinterpret_cast<const v4d*>(vec + o * T + (m * 4 + g) * 4);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[o][n] = fma(row[n][e], wv[e], part[o][n]);
+        }
+}
+// rhs[o][base + 16 n + r] += sign * (part[o][n] summed over the four lane groups), rows >= nrows do not exist
+__device__ __forceinline__ void rhs_apply(double* rhs, size_t pitch, const double (&part)[4][4], int base, int r, int g,
+                                          int nrows, int nout, double sign) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < nout) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                double t = part[o][n];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                const int idx = base + 16 * n + r;
+                if (g == 0 && idx < nrows) {
+                    double* q = rhs + (size_t)o * pitch + idx;
+                    st_l2(q, fma(sign, t, ld_l2(q)));
+                }
+            }
+        }
+}
+
 // Cholesky factor and inverse of one 64 x 64 diagonal block by ONE wave, rows in registers: lane r holds row r of the
 // block (64 doubles).  A column step parks the scaled column in LDS and every lane reads it back with uniform addresses
 // (a broadcast, two values per ds_read_b128); the substitution reads L the same way.  No barrier inside either loop
@@ -439,13 +485,23 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
     __shared__ double S[T * LD];
     __shared__ double X[T * LD];
     __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
+    __shared__ __attribute__((aligned(32))) double wj[kMaxOut * T];
     __shared__ int ok;
     const int b = matrix_of(p, blockIdx.x), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nb = nblocks(p.n[b]);
+    const int nrows = p.n[b], nb = nblocks(nrows), nout = p.nout;
     const size_t ld = p.ld;
     double* K = p.K + (size_t)b * ld * ld;
     double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
+    // forward substitution of the right-hand sides, in place in the alpha buffer: it starts as y, block j becomes
+    // w_j = Dinv_j s_j when column j's diagonal block is factored, and every tile L[i][j] then takes L[i][j] w_j off block i
+    double* rhs = p.alpha + (size_t)b * nout * p.nmax;
+    {
+        const double* yb = p.y + (size_t)b * nout * p.nmax;
+        for (int o = 0; o < nout; ++o)
+            for (int e = tid; e < nrows; e += 256) st_l2(rhs + (size_t)o * p.nmax + e, yb[(size_t)o * p.nmax + e]);
+    }
     if (tid == 0) ok = 1;
+    __threadfence_block();
     __syncthreads();
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const int r = lane & 15, g = lane >> 4;
@@ -482,6 +538,15 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
                             for (int e = 0; e < 4; ++e) S[(16 * n + r) * LD + 16 * m + 4 * e + g] = acc[m][n][e];
                     // same wave, and LDS operations of one wave complete in order: no barrier before the re-read
                     chol_trinv_wave(S, X, stage, lane, &ok);
+                    for (int o = 0; o < nout; ++o) {
+                        const int row = j * T + lane;
+                        const double sj = row < nrows ? ld_l2(rhs + (size_t)o * p.nmax + row) : 0.0;
+                        double w = 0.0;
+#pragma unroll
+                        for (int k = 0; k < T; ++k) w = fma(X[lane * LD + k], readlane_f64(sj, k), w);
+                        wj[o * T + rhs_slot(lane)] = w;
+                        if (row < nrows) st_l2(rhs + (size_t)o * p.nmax + row, w);
+                    }
                 }
                 __syncthreads();
                 for (int e = tid; e < T * T; e += 256) {
@@ -491,6 +556,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
                 }
             }
             if (!diag_wave) {
+                double part[4][4] = {};
                 left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
                     if (!mine) return;
 #pragma unroll
@@ -498,7 +564,9 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g] = row[n][e];
+                    rhs_accumulate(part, row, wj, m, g, nout);
                 });
+                if (mine) rhs_apply(rhs, p.nmax, part, i * T, r, g, nrows, nout, -1.0);
             }
         }
         __threadfence_block();
@@ -518,6 +586,11 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
     double* U = p.U + (size_t)b * ld * ld;
     const double* Dinv = p.Dinv + (size_t)b * p.nb_max * T * T;
     const int r = lane & 15, g = lane >> 4;
+    // alpha = U w in place in the alpha buffer, which gp_potrf_cols left holding w = L^-1 y: in column c block c becomes
+    // Dinv_c^T w_c and every tile U[a][c] adds U[a][c] w_c to block a
+    __shared__ __attribute__((aligned(32))) double wc[kMaxOut * T];
+    const int nrows = p.n[b], nout = p.nout;
+    double* rhs = p.alpha + (size_t)b * nout * p.nmax;
     for (int c = 0; c < nb; ++c) {
         for (int e = tid; e < T * T; e += 256) {
             const int rr = e / T, cc = e % T;
@@ -526,7 +599,17 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
             U[(size_t)(c * T + cc) * ld + c * T + rr] = d;                     // U[c][c] = Dinv_c^T
             if (c & 1) U[(size_t)(c * T + rr) * ld + (c - 1) * T + cc] = 0.0;  // gp_kinv_trace starts 128-aligned
         }
+        if (tid < T)
+            for (int o = 0; o < nout; ++o)
+                wc[o * T + rhs_slot(tid)] = c * T + tid < nrows ? ld_l2(rhs + (size_t)o * p.nmax + c * T + tid) : 0.0;
         __syncthreads();
+        if (tid < T && c * T + tid < nrows)
+            for (int o = 0; o < nout; ++o) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < T; ++k) t = fma(X[k * LD + tid], wc[o * T + rhs_slot(k)], t);
+                st_l2(rhs + (size_t)o * p.nmax + c * T + tid, t);
+            }
         for (int a0 = 0; a0 < c; a0 += 4) {
             const bool mine = a0 + wave < c;
             const int a = mine ? a0 + wave : c - 1;
@@ -539,6 +622,7 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
             panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a, stage, tid, lane);
+            double part[4][4] = {};
             left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
                 if (!mine) return;
 #pragma unroll
@@ -546,7 +630,9 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         U[(size_t)(a * T + 16 * n + r) * ld + c * T + 16 * m + 4 * e + g] = row[n][e];
+                rhs_accumulate(part, row, wc, m, g, nout);
             });
+            if (mine) rhs_apply(rhs, p.nmax, part, a * T, r, g, nrows, nout, 1.0);
         }
         __threadfence_block();
         __syncthreads();
@@ -567,8 +653,13 @@ __host__ __device__ inline int kinv_strips(int nb) {  // strips of a matrix with
     return s;
 }
 
+__device__ __forceinline__ double* gp_wbuf(const GpParams& p, int b) { return p.Dinv + (size_t)b * p.nb_max * T * T; }
+__device__ __forceinline__ double* gp_share(const GpParams& p, int b) { return gp_wbuf(p, b) + (size_t)p.nout * p.ld; }
+// per-strip partial sums of alpha^T Krbf alpha and alpha^T (Krbf o d^2) alpha, behind the per-block shares
+__device__ __forceinline__ double* gp_quad_share(const GpParams& p, int b) { return gp_share(p, b) + 5 * (size_t)p.nb_max; }
+
 __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double* kinv_out) {
-    __shared__ double red[3][4];
+    __shared__ double red[5][4];
     __shared__ __attribute__((aligned(16))) double stage[2 * T * LDB];
     // XCD-aware mapping.  Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with a
     // (strip, matrix) grid one matrix's strips would land on all eight.  Here ids that are congruent mod 8 -- the ones
@@ -607,62 +698,90 @@ __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double
     // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = tb*64 + 16 nn + r (own rows)
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     const double* x = p.x + (size_t)b * p.nmax;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, q0 = 0.0, q1 = 0.0;
     const double wgt = (ta == tb) ? 1.0 : 2.0;
     if (mine) {
+        // The quadratic forms alpha^T (dK/dtheta) alpha ride along: every pair (gr, gc) meets its Krbf and d^2 here anyway
+        // (alpha is complete before this kernel is launched; summed over the outputs, like the traces).
+        const double* al = p.alpha + (size_t)b * p.nout * p.nmax;
+        const bool quad = p.grad != nullptr;
+        double ac[kMaxOut][4];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) {
+                const int gc = tb * T + 16 * nn + r;
+                ac[o][nn] = (quad && o < p.nout && gc < n) ? al[(size_t)o * p.nmax + gc] : 0.0;
+            }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int nn = 0; nn < 4; ++nn)
+            for (int e = 0; e < 4; ++e) {
+                const int gr = ta * T + 16 * m + 4 * e + g;
+                double ar[kMaxOut];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int gr = ta * T + 16 * m + 4 * e + g, gc = tb * T + 16 * nn + r;
+                for (int o = 0; o < kMaxOut; ++o) ar[o] = (quad && o < p.nout && gr < n) ? al[(size_t)o * p.nmax + gr] : 0.0;
+                const double xr = gr < n ? x[gr] : 0.0;
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const int gc = tb * T + 16 * nn + r;
                     const double v = -acc[m][nn][e];
                     if (gr < n && gc < n) {
-                        const double d = (x[gr] - x[gc]) * inv_l;
+                        const double d = (xr - x[gc]) * inv_l;
                         const double d2 = d * d;
                         const double kr = c * exp(-0.5 * d2);
                         t0 += wgt * v * kr;
                         t1 += wgt * v * kr * d2;
                         if (gr == gc) t2 += v;
+                        double aa = ar[0] * ac[0][nn];
+#pragma unroll
+                        for (int o = 1; o < kMaxOut; ++o) aa = fma(ar[o], ac[o][nn], aa);
+                        const double qk = wgt * kr * aa;
+                        q0 += qk;
+                        q1 += qk * d2;
                     }
                     if (kinv_out && gr < nrows && gc < nrows) {
                         kinv_out[(size_t)b * ld * ld + (size_t)gr * ld + gc] = v;
                         kinv_out[(size_t)b * ld * ld + (size_t)gc * ld + gr] = v;
                     }
                 }
+            }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         t0 += __shfl_xor(t0, off);
         t1 += __shfl_xor(t1, off);
         t2 += __shfl_xor(t2, off);
+        q0 += __shfl_xor(q0, off);
+        q1 += __shfl_xor(q1, off);
     }
     if (lane == 0) {
         red[0][wave] = t0;
         red[1][wave] = t1;
         red[2][wave] = t2;
+        red[3][wave] = q0;
+        red[4][wave] = q1;
     }
     __syncthreads();
-    if (tid < 3) {
+    if (tid < 5) {
         // one slot per strip, summed in strip order by gp_finish: bitwise reproducible, unlike an atomic accumulation
         const int ntiles = p.nb_max * (p.nb_max + 1) / 2;
-        p.tr[((size_t)b * 3 + tid) * ntiles + strip] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        const double v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        if (tid < 3)
+            p.tr[((size_t)b * 3 + tid) * ntiles + strip] = v;
+        else
+            gp_quad_share(p, b)[(size_t)(tid - 3) * nstrip_grid + strip] = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// alpha = U (U^T y), lml, gradient assembly: three small kernels, nb workgroups per matrix for the O(n^2) parts.
-//   gp_w      w = U^T y for one 64-column block        (thread per column, 8 rows in flight per thread)
-//   gp_alpha  alpha for one 64-row block + that block's share of y.alpha, log-det, alpha^T dK alpha
-//   gp_finish sums the per-block shares in block order (deterministic) -> lml, gradient
+// alpha = U (U^T y) for the row-ordered inverse, lml, gradient assembly: small kernels, nb workgroups per matrix.
+//   gp_w      w = U^T y for one 64-column block        (thread per column, 8 rows in flight per thread; row order only)
+//   gp_alpha  alpha for one 64-row block (row order; the column-ordered kernels have left it in place) + that block's
+//             share of y.alpha, log-det, alpha.alpha
+//   gp_finish sums the per-block and per-strip shares in order (deterministic) -> lml, gradient
 // w lives in the Dinv buffer (free once gp_trtri has run); per-block shares go to the tail of the same buffer.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double* gp_wbuf(const GpParams& p, int b) { return p.Dinv + (size_t)b * p.nb_max * T * T; }
-__device__ __forceinline__ double* gp_share(const GpParams& p, int b) { return gp_wbuf(p, b) + (size_t)p.nout * p.ld; }
-
-constexpr int kMaxOut = 4;  // ste_gp_batch_f64.nout <= 4
-
 __global__ __launch_bounds__(64) void gp_w(const GpParams p) {
     const int b = matrix_of(p, blockIdx.y), kb = blockIdx.x, lane = threadIdx.x;
     const int n = p.n[b], nb = nblocks(n);
@@ -715,7 +834,19 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
     const double* yb = p.y + (size_t)b * p.nout * p.nmax;
     const double* wb = gp_wbuf(p, b);
     double* alb = p.alpha + (size_t)b * p.nout * p.nmax;
-    for (int r = wave; r < T; r += 4) {
+    if (p.inverse_cols) {
+        // gp_trtri_cols left alpha in place: only the shares remain
+        const int a = ab * T + tid;
+        if (tid < T && a < n) {
+            for (int o = 0; o < p.nout; ++o) {
+                const double t = alb[(size_t)o * p.nmax + a];
+                yta += yb[(size_t)o * p.nmax + a] * t;
+                q2 += t * t;
+            }
+            sl += log(L[(size_t)a * ld + a]);
+        }
+    }
+    for (int r = wave; r < T && !p.inverse_cols; r += 4) {
         const int a = ab * T + r;
         if (a >= n) continue;
         double acc[kMaxOut] = {0.0, 0.0, 0.0, 0.0};
@@ -752,10 +883,7 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
         }
         if (lane == 0) sl += log(L[(size_t)a * ld + a]);
     }
-    if (p.grad) {
-        // alpha^T (dK/dtheta) alpha restricted to the rows of this block needs the whole alpha vector, which the other
-        // blocks of the grid are still producing: gp_quad (next launch) does it.
-    }
+    // (alpha^T (dK/dtheta) alpha needs the whole alpha vector: gp_kinv_trace, launched next, reduces it with the traces)
     double vals[5] = {yta, sl, q0, q1, q2};
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
@@ -769,51 +897,6 @@ __global__ __launch_bounds__(256) void gp_alpha(const GpParams p) {
     (void)x; (void)c; (void)inv_l;
 }
 
-// alpha^T Krbf alpha and alpha^T (Krbf o d^2) alpha summed over the outputs: rows of one 64-row block against the columns
-// j <= i (the form is symmetric: pairs below the diagonal count twice), one exp per pair shared by all outputs.
-__global__ __launch_bounds__(256) void gp_quad(const GpParams p) {
-    __shared__ double red[2][4];
-    const int b = matrix_of(p, blockIdx.y), ab = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = p.n[b], nb = nblocks(n);
-    if (ab >= nb) return;
-    const double* x = p.x + (size_t)b * p.nmax;
-    const double* al = p.alpha + (size_t)b * p.nout * p.nmax;
-    const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
-    double q0 = 0.0, q1 = 0.0;
-    for (int r = wave; r < T; r += 4) {
-        const int i = ab * T + r;
-        if (i >= n) continue;
-        const double xi = x[i];
-        double ai[kMaxOut];
-#pragma unroll
-        for (int o = 0; o < kMaxOut; ++o) ai[o] = o < p.nout ? al[(size_t)o * p.nmax + i] : 0.0;
-        double r0 = 0.0, r1 = 0.0;
-        for (int j = lane; j <= i; j += 64) {
-            const double d = (xi - x[j]) * inv_l, d2 = d * d;
-            double aa = 0.0;
-#pragma unroll
-            for (int o = 0; o < kMaxOut; ++o)
-                if (o < p.nout) aa = fma(ai[o], al[(size_t)o * p.nmax + j], aa);
-            const double kr = (j < i ? 2.0 : 1.0) * c * exp(-0.5 * d2) * aa;
-            r0 += kr;
-            r1 += kr * d2;
-        }
-        q0 += r0;
-        q1 += r1;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        q0 += __shfl_xor(q0, off);
-        q1 += __shfl_xor(q1, off);
-    }
-    if (lane == 0) {
-        red[0][wave] = q0;
-        red[1][wave] = q1;
-    }
-    __syncthreads();
-    if (tid < 2) gp_share(p, b)[(size_t)(2 + tid) * p.nb_max + ab] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-}
-
 __global__ __launch_bounds__(64) void gp_finish(const GpParams p) {
     const int bslot = blockIdx.x * 64 + threadIdx.x;
     if (bslot >= p.nslots) return;
@@ -825,12 +908,17 @@ __global__ __launch_bounds__(64) void gp_finish(const GpParams p) {
         for (int i = 0; i < nb; ++i) r[v] += sh[(size_t)v * p.nb_max + i];
     p.lml[b] = -0.5 * r[0] - nout * r[1] - nout * (0.5 * n) * kLog2Pi;
     if (p.grad) {
-        const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = kinv_strips(nb);
+        const int ntiles = p.nb_max * (p.nb_max + 1) / 2, mine = kinv_strips(nb), nstrip_grid = kinv_strips(p.nb_max);
         double tr[3];
         for (int v = 0; v < 3; ++v) {
             double acc = 0.0;
             for (int i = 0; i < mine; ++i) acc += p.tr[((size_t)b * 3 + v) * ntiles + i];
             tr[v] = acc;
+        }
+        for (int v = 0; v < 2; ++v) {  // the quadratic forms, one share per strip of gp_kinv_trace
+            double acc = 0.0;
+            for (int i = 0; i < mine; ++i) acc += gp_quad_share(p, b)[(size_t)v * nstrip_grid + i];
+            r[2 + v] = acc;
         }
         const double s = exp(p.theta[b * 3 + 2]);
         p.grad[b * 3 + 0] = 0.5 * (r[2] - nout * tr[0]);
@@ -1030,13 +1118,14 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
         hipLaunchKernelGGL(stegp::gp_trtri_cols, dim3(ns), dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL(stegp::gp_trtri_rows, dim3(p.nb_max, ns), dim3(256), 0, s, p);
+    // alpha first: gp_kinv_trace reduces alpha^T (dK/dtheta) alpha along with the traces.  The column-ordered kernels
+    // leave alpha in place (gp_potrf_cols: w = L^-1 y, gp_trtri_cols: alpha = U w); the row-ordered inverse needs gp_w.
+    if (!p.inverse_cols) hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, ns), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     if (p.grad || b->Kinv) {
         const unsigned groups = (ns + 7) / 8, strips = (unsigned)stegp::kinv_strips(p.nb_max);
         hipLaunchKernelGGL(stegp::gp_kinv_trace, dim3(groups * 8u * strips), dim3(256), 0, s, p, b->Kinv);
     }
-    hipLaunchKernelGGL(stegp::gp_w, dim3(p.nb_max, ns), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_alpha, dim3(p.nb_max, ns), dim3(256), 0, s, p);
-    if (p.grad) hipLaunchKernelGGL(stegp::gp_quad, dim3(p.nb_max, ns), dim3(256), 0, s, p);
     hipLaunchKernelGGL(stegp::gp_finish, dim3((ns + 63) / 64), dim3(64), 0, s, p);
     return gp_hip(hipGetLastError(), "gp_lml launch");
 }
