@@ -254,13 +254,14 @@ __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int
         *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -st[q];  // the panel is staged NEGATED
     }
 }
-// acc[m][n] += shared[16 m + ..][k] * own[16 n + ..][k] for one 16-k sub-block; shared fragments come from LDS
+// acc[m][n] += shared[16 m + ..][k] * own_n[..][k] for one 16-k sub-block; shared fragments come from LDS.  Only the first
+// `nlive` of the wave's four own strips take part (4 in the steady state: one basic block of 64 MFMAs).
 __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
-                                        bool live) {
+                                        int nlive) {
     v4d a[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
-    if (live) {
+    if (nlive >= 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -268,15 +269,28 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (n < nlive) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+            }
     }
 }
 // accT -= sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T (both callers subtract the product, so
 // the shared panel is negated once on its way into LDS).  `shared` points at row 0 / column 0
-// of the shared 64-row panel; this wave only accumulates blocks >= wb0 (its operand is structurally zero before that).
+// of the shared 64-row panel.  A wave's four own strips are 16 rows of FOUR DIFFERENT tiles (own[n] = strip `wave` of
+// the pass's n-th tile), so that the four waves of a pass always carry the same load: strip n joins at block wb0 + n
+// (before that its operand is structurally zero -- or not yet written) and strips n >= cap belong to tiles the pass
+// does not have (the last pass of a column).  A pass with t < 4 tiles costs t/4 of a full one instead of a full one.
 // Every thread of the workgroup must call this with the same kb0, kb1 (it contains barriers).
 __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
-                                             const double* const (&own)[4], int kb0, int kb1, int wb0, double* stage,
-                                             int tid, int lane) {
+                                             const double* const (&own)[4], int kb0, int kb1, int wb0, int cap,
+                                             double* stage, int tid, int lane) {
     if (kb0 >= kb1) return;
     const int r = lane & 15, g = lane >> 4;
     v4d st[4];
@@ -291,16 +305,17 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
     for (int kb = kb0; kb < kb1; ++kb) {
         double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
-        const bool more = kb + 1 < kb1, live = kb >= wb0;
+        const bool more = kb + 1 < kb1;
+        const int nlive = min(cap, kb - wb0 + 1);
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
         stage_load(st, shared + (size_t)kn, lds_ld, tid);
-        mma_sub(acc, cur, 0, f0, r, g, live);
+        mma_sub(acc, cur, 0, f0, r, g, nlive);
         load_rows(f0, own, kn);
-        mma_sub(acc, cur, 1, f1, r, g, live);
+        mma_sub(acc, cur, 1, f1, r, g, nlive);
         load_rows(f1, own, kn + 16);
-        mma_sub(acc, cur, 2, f2, r, g, live);
+        mma_sub(acc, cur, 2, f2, r, g, nlive);
         load_rows(f2, own, kn + 32);
-        mma_sub(acc, cur, 3, f3, r, g, live);
+        mma_sub(acc, cur, 3, f3, r, g, nlive);
         load_rows(f3, own, kn + 48);
         stage_store(nxt, st, tid);
         __syncthreads();
@@ -309,15 +324,31 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
 // The same contraction in at most 256 VGPRs, for kernels that run two workgroups per CU (two waves per SIMD): two
 // rotating fragment sets instead of four, the shared fragments read one block row at a time, the staged panel held in
 // two halves.  Each wave prefetches less far ahead, but the second wave on the SIMD keeps the MFMA pipe busy meanwhile.
-__device__ __forceinline__ void mma_sub_lean(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g) {
+template <bool kFull>
+__device__ __forceinline__ void mma_sub_lean(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
+                                             int nlive) {
+    if (kFull) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const v4d a = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
+        for (int m = 0; m < 4; ++m) {
+            const v4d a = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], own.v[n][e], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], own.v[n][e], acc[m][n], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            if (n < nlive) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const v4d a = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], own.v[n][e], acc[m][n], 0, 0, 0);
+                }
+            }
     }
 }
 __device__ __forceinline__ void stage_half(double* dst, const double* src, size_t ld, int tid, int half) {
@@ -328,9 +359,12 @@ __device__ __forceinline__ void stage_half(double* dst, const double* src, size_
         *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -v;
     }
 }
+// (nlive is fixed for the pass here; kFull = all four strips live: the two cases are separate loops, because one loop with
+//  both bodies does not fit the 256 registers of two workgroups per CU)
+template <bool kFull>
 __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
-                                                  const double* const (&own)[4], int kb0, int kb1, double* stage, int tid,
-                                                  int lane) {
+                                                  const double* const (&own)[4], int kb0, int kb1, int nlive, double* stage,
+                                                  int tid, int lane) {
     if (kb0 >= kb1) return;
     const int r = lane & 15, g = lane >> 4;
     stage_half(stage, shared + (size_t)kb0 * T, lds_ld, tid, 0);
@@ -343,15 +377,15 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
         double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
         const int kn = (kb + 1 < kb1 ? kb + 1 : kb0) * T;  // refills past the end re-read the first block and are dropped
-        mma_sub_lean(acc, cur, 0, f0, r, g);
+        mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
         load_rows(f0, own, kb * T + 32);
         stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 0);
-        mma_sub_lean(acc, cur, 1, f1, r, g);
+        mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
         load_rows(f1, own, kb * T + 48);
-        mma_sub_lean(acc, cur, 2, f0, r, g);
+        mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
         load_rows(f0, own, kn);
         stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 1);
-        mma_sub_lean(acc, cur, 3, f1, r, g);
+        mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
         load_rows(f1, own, kn + 16);
         __syncthreads();
     }
@@ -407,9 +441,10 @@ __device__ __forceinline__ void rhs_accumulate(double (&part)[4][4], const v4d (
                 for (int e = 0; e < 4; ++e) part[o][n] = fma(row[n][e], wv[e], part[o][n]);
         }
 }
-// rhs[o][base + 16 n + r] += sign * (part[o][n] summed over the four lane groups), rows >= nrows do not exist
+// rhs[o][base + 64 n + r] += sign * (part[o][n] summed over the four lane groups) for the strips n0 <= n < n1 (strip n of a
+// wave lies in the pass's n-th tile); rows >= nrows do not exist
 __device__ __forceinline__ void rhs_apply(double* rhs, size_t pitch, const double (&part)[4][4], int base, int r, int g,
-                                          int nrows, int nout, double sign) {
+                                          int nrows, int nout, double sign, int n0, int n1) {
 #pragma unroll
     for (int o = 0; o < 4; ++o)
         if (o < nout) {
@@ -418,8 +453,8 @@ __device__ __forceinline__ void rhs_apply(double* rhs, size_t pitch, const doubl
                 double t = part[o][n];
                 t += __shfl_xor(t, 16);
                 t += __shfl_xor(t, 32);
-                const int idx = base + 16 * n + r;
-                if (g == 0 && idx < nrows) {
+                const int idx = base + T * n + r;
+                if (g == 0 && n >= n0 && n < n1 && idx < nrows) {
                     double* q = rhs + (size_t)o * pitch + idx;
                     st_l2(q, fma(sign, t, ld_l2(q)));
                 }
@@ -506,15 +541,21 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const int r = lane & 15, g = lane >> 4;
     for (int j = 0; j < nb; ++j) {
-        // Tiles of block column j, four per pass, one per wave; the first pass starts at the diagonal tile itself:
+        // Tiles of block column j, four per pass, starting at the diagonal tile; every wave takes strip `wave` (16 rows) of
+        // each of them:
         //   T(i) = K[i][j] - sum_{k<j} L[i][k] L[j][k]^T;   L[j][j] = chol(T(j));   L[i][j]^T = Dinv_j * T(i)^T
         for (int i0 = j; i0 < nb; i0 += 4) {
-            const bool mine = i0 + wave < nb;
-            const int i = mine ? i0 + wave : nb - 1;
+            const int ntile = min(4, nb - i0);
+            // the identity padding of the last tile has nothing to accumulate (its rows of L are zero left of the diagonal)
+            const int cap = ntile - ((i0 + ntile == nb && (nb - 1) * T + 16 * wave >= nrows) ? 1 : 0);
             const double* own[4];
+            size_t row0[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) own[n] = K + (size_t)(i * T + r + 16 * n) * ld + 4 * g;
-            // acc[m][n][e] is element (jj = 16 m + 4 e + g, ii = 16 n + r) of the transposed tile; it starts as K[i][j]^T
+            for (int n = 0; n < 4; ++n) {
+                row0[n] = (size_t)(min(i0 + n, nb - 1) * T + 16 * wave + r) * ld;  // tiles the pass lacks: clamped, never stored
+                own[n] = K + row0[n] + 4 * g;
+            }
+            // acc[m][n][e] is element (jj = 16 m + 4 e + g, row r of strip n) of the transposed tiles; it starts as K[i][j]^T
             // (loads in flight behind the first panel blocks) and the negated panel products are accumulated onto it
             v4d acc[4][4];
 #pragma unroll
@@ -522,21 +563,19 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[m][n][e] = K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g];
-            // (first live block passed as a run-time value: with a literal 0 hipcc merges the four sub-blocks of the panel loop
+                    for (int e = 0; e < 4; ++e) acc[m][n][e] = K[row0[n] + j * T + 16 * m + 4 * e + g];
+            // (first live block passed as a run-time value: with a literal hipcc merges the four sub-blocks of the panel loop
             //  into one basic block and then shuffles 160 accumulator registers between AGPRs and VGPRs per iteration)
-            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, p.nb_max < 0, stage, tid, lane);
-            const bool diag_wave = (i0 == j) && wave == 0;
-            if (i0 == j) {
-                if (diag_wave) {
+            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, (p.nb_max < 0) - 3, cap, stage, tid, lane);
+            const bool first = i0 == j;
+            if (first) {
+                // strip 0 of every wave is its quarter of the diagonal tile
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int n = 0; n < 4; ++n)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) S[(16 * n + r) * LD + 16 * m + 4 * e + g] = acc[m][n][e];
-                    // same wave, and LDS operations of one wave complete in order: no barrier before the re-read
+                    for (int e = 0; e < 4; ++e) S[(16 * wave + r) * LD + 16 * m + 4 * e + g] = acc[m][0][e];
+                __syncthreads();
+                if (wave == 0) {
                     chol_trinv_wave(S, X, stage, lane, &ok);
                     for (int o = 0; o < nout; ++o) {
                         const int row = j * T + lane;
@@ -555,18 +594,19 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
                     Dinv[(size_t)j * T * T + e] = X[rr * LD + cc];
                 }
             }
-            if (!diag_wave) {
+            const int n0 = first ? 1 : 0;
+            if (n0 < ntile) {
                 double part[4][4] = {};
                 left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
-                    if (!mine) return;
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
+                        if (n >= n0 && n < ntile) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            K[(size_t)(i * T + 16 * n + r) * ld + j * T + 16 * m + 4 * e + g] = row[n][e];
+                            for (int e = 0; e < 4; ++e) K[row0[n] + j * T + 16 * m + 4 * e + g] = row[n][e];
+                        }
                     rhs_accumulate(part, row, wj, m, g, nout);
                 });
-                if (mine) rhs_apply(rhs, p.nmax, part, i * T, r, g, nrows, nout, -1.0);
+                rhs_apply(rhs, p.nmax, part, i0 * T + 16 * wave, r, g, nrows, nout, -1.0, n0, ntile);
             }
         }
         __threadfence_block();
@@ -611,28 +651,33 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
                 st_l2(rhs + (size_t)o * p.nmax + c * T + tid, t);
             }
         for (int a0 = 0; a0 < c; a0 += 4) {
-            const bool mine = a0 + wave < c;
-            const int a = mine ? a0 + wave : c - 1;
+            // tiles a0 .. a0+3 of column c, strip `wave` of each: tile a0+n joins at block a0+n (U[a][k] = 0 for k < a, and
+            // that part of U is not even written), so the four waves carry the same load through the pass's triangle
+            const int ntile = min(4, c - a0);
             const double* own[4];
+            size_t row0[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) own[n] = U + (size_t)(a * T + r + 16 * n) * ld + 4 * g;
+            for (int n = 0; n < 4; ++n) {
+                row0[n] = (size_t)(min(a0 + n, c - 1) * T + 16 * wave + r) * ld;
+                own[n] = U + row0[n] + 4 * g;
+            }
             v4d acc[4][4];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-            panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a, stage, tid, lane);
+            panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a0, ntile, stage, tid, lane);
             double part[4][4] = {};
             left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
-                if (!mine) return;
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
+                    if (n < ntile) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        U[(size_t)(a * T + 16 * n + r) * ld + c * T + 16 * m + 4 * e + g] = row[n][e];
+                        for (int e = 0; e < 4; ++e) U[row0[n] + c * T + 16 * m + 4 * e + g] = row[n][e];
+                    }
                 rhs_accumulate(part, row, wc, m, g, nout);
             });
-            if (mine) rhs_apply(rhs, p.nmax, part, a * T, r, g, nrows, nout, 1.0);
+            rhs_apply(rhs, p.nmax, part, a0 * T + 16 * wave, r, g, nrows, nout, 1.0, 0, ntile);
         }
         __threadfence_block();
         __syncthreads();
@@ -680,27 +725,28 @@ __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double
         ++ta;
     }
     if (ta >= nb) return;
-    const int tb0 = 4 * (strip - first);
-    const bool mine = tb0 + wave <= ta;
-    const int tb = mine ? tb0 + wave : ta;
+    // tiles tb0 .. tb0+3 (those with tb <= ta), strip `wave` of each per wave: a strip with t < 4 tiles costs t/4 of a full one
+    const int tb0 = 4 * (strip - first), ntile = min(4, ta - tb0 + 1);
     const size_t ld = p.ld;
     const double* U = p.U + (size_t)b * ld * ld;
     const int r = lane & 15, g = lane >> 4, nrows = nb * T;
     const double* own[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) own[m] = U + (size_t)(tb * T + r + 16 * m) * ld + 4 * g;
+    for (int nn = 0; nn < 4; ++nn) own[nn] = U + (size_t)(min(tb0 + nn, ta) * T + 16 * wave + r) * ld + 4 * g;
     v4d acc[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) acc[m][nn] = v4d{0.0, 0.0, 0.0, 0.0};
-    panel_gemm_t_lean(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, stage, tid, lane);
-    // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = tb*64 + 16 nn + r (own rows)
+    if (ntile == 4)
+        panel_gemm_t_lean<true>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, 4, stage, tid, lane);
+    else
+        panel_gemm_t_lean<false>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, ntile, stage, tid, lane);
+    // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = (tb0+nn)*64 + 16 wave + r (own rows)
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     const double* x = p.x + (size_t)b * p.nmax;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, q0 = 0.0, q1 = 0.0;
-    const double wgt = (ta == tb) ? 1.0 : 2.0;
-    if (mine) {
+    {
         // The quadratic forms alpha^T (dK/dtheta) alpha ride along: every pair (gr, gc) meets its Krbf and d^2 here anyway
         // (alpha is complete before this kernel is launched; summed over the outputs, like the traces).
         const double* al = p.alpha + (size_t)b * p.nout * p.nmax;
@@ -710,8 +756,8 @@ __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double
         for (int o = 0; o < kMaxOut; ++o)
 #pragma unroll
             for (int nn = 0; nn < 4; ++nn) {
-                const int gc = tb * T + 16 * nn + r;
-                ac[o][nn] = (quad && o < p.nout && gc < n) ? al[(size_t)o * p.nmax + gc] : 0.0;
+                const int gc = (tb0 + nn) * T + 16 * wave + r;
+                ac[o][nn] = (quad && o < p.nout && nn < ntile && gc < n) ? al[(size_t)o * p.nmax + gc] : 0.0;
             }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -724,7 +770,9 @@ __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double
                 const double xr = gr < n ? x[gr] : 0.0;
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
-                    const int gc = tb * T + 16 * nn + r;
+                    if (nn >= ntile) continue;
+                    const int gc = (tb0 + nn) * T + 16 * wave + r;
+                    const double wgt = (tb0 + nn == ta) ? 1.0 : 2.0;
                     const double v = -acc[m][nn][e];
                     if (gr < n && gc < n) {
                         const double d = (xr - x[gc]) * inv_l;
