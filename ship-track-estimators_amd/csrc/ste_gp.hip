@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/ste.h"
 
@@ -256,12 +257,13 @@ __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int
 }
 // acc[m][n] += shared[16 m + ..][k] * own_n[..][k] for one 16-k sub-block; shared fragments come from LDS.  Only the first
 // `nlive` of the wave's four own strips take part (4 in the steady state: one basic block of 64 MFMAs).
+template <bool kFull>
 __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
                                         int nlive) {
     v4d a[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
-    if (nlive >= 4) {
+    if (kFull) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -302,24 +304,31 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
     load_rows(f3, own, kb0 * T + 48);
     stage_store(stage, st, tid);
     __syncthreads();
-    for (int kb = kb0; kb < kb1; ++kb) {
+    auto block = [&](auto full, int kb) {
+        constexpr bool kFull = decltype(full)::value;
         double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
         const bool more = kb + 1 < kb1;
         const int nlive = min(cap, kb - wb0 + 1);
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
         stage_load(st, shared + (size_t)kn, lds_ld, tid);
-        mma_sub(acc, cur, 0, f0, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive);
         load_rows(f0, own, kn);
-        mma_sub(acc, cur, 1, f1, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive);
         load_rows(f1, own, kn + 16);
-        mma_sub(acc, cur, 2, f2, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive);
         load_rows(f2, own, kn + 32);
-        mma_sub(acc, cur, 3, f3, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive);
         load_rows(f3, own, kn + 48);
         stage_store(nxt, st, tid);
         __syncthreads();
-    }
+    };
+    // Two loops, not one with both bodies: with the partial and the full MFMA sequences in one loop the accumulators of the
+    // two paths get different registers and 768 v_accvgpr_mov per block to reconcile them.  The first covers the blocks in
+    // which fewer than four strips are live (the pass's triangle, or all of a short pass), the second is the steady state.
+    int kb = kb0;
+    for (; kb < kb1 && min(cap, kb - wb0 + 1) < 4; ++kb) block(std::false_type{}, kb);
+    for (; kb < kb1; ++kb) block(std::true_type{}, kb);
 }
 // The same contraction in at most 256 VGPRs, for kernels that run two workgroups per CU (two waves per SIMD): two
 // rotating fragment sets instead of four, the shared fragments read one block row at a time, the staged panel held in
