@@ -259,7 +259,7 @@ __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int
 // `nlive` of the wave's four own strips take part (4 in the steady state: one basic block of 64 MFMAs).
 template <bool kFull>
 __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
-                                        int nlive) {
+                                        int nlive, int mcap) {
     v4d a[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
@@ -272,14 +272,17 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
     } else {
+        // own strips n >= nlive and shared 16-row groups m >= mcap (the zero padding of the last panel) stay out
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+        for (int n = 0; n < 4; ++n)
             if (n < nlive) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int m = 0; m < 4; ++m)
+                    if (m < mcap) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+                        for (int e = 0; e < 4; ++e)
+                            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+                    }
             }
     }
 }
@@ -289,9 +292,10 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
 // the pass's n-th tile), so that the four waves of a pass always carry the same load: strip n joins at block wb0 + n
 // (before that its operand is structurally zero -- or not yet written) and strips n >= cap belong to tiles the pass
 // does not have (the last pass of a column).  A pass with t < 4 tiles costs t/4 of a full one instead of a full one.
+// mcap < 4: only the first mcap 16-row groups of the shared panel are real (the last block row of a padded matrix).
 // Every thread of the workgroup must call this with the same kb0, kb1 (it contains barriers).
 __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
-                                             const double* const (&own)[4], int kb0, int kb1, int wb0, int cap,
+                                             const double* const (&own)[4], int kb0, int kb1, int wb0, int cap, int mcap,
                                              double* stage, int tid, int lane) {
     if (kb0 >= kb1) return;
     const int r = lane & 15, g = lane >> 4;
@@ -312,13 +316,13 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         const int nlive = min(cap, kb - wb0 + 1);
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
         stage_load(st, shared + (size_t)kn, lds_ld, tid);
-        mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive, mcap);
         load_rows(f0, own, kn);
-        mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive, mcap);
         load_rows(f1, own, kn + 16);
-        mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive, mcap);
         load_rows(f2, own, kn + 32);
-        mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive);
+        mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive, mcap);
         load_rows(f3, own, kn + 48);
         stage_store(nxt, st, tid);
         __syncthreads();
@@ -327,7 +331,7 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
     // two paths get different registers and 768 v_accvgpr_mov per block to reconcile them.  The first covers the blocks in
     // which fewer than four strips are live (the pass's triangle, or all of a short pass), the second is the steady state.
     int kb = kb0;
-    for (; kb < kb1 && min(cap, kb - wb0 + 1) < 4; ++kb) block(std::false_type{}, kb);
+    for (; kb < kb1 && (mcap < 4 || min(cap, kb - wb0 + 1) < 4); ++kb) block(std::false_type{}, kb);
     for (; kb < kb1; ++kb) block(std::true_type{}, kb);
 }
 // The same contraction in at most 256 VGPRs, for kernels that run two workgroups per CU (two waves per SIMD): two
@@ -372,8 +376,8 @@ __device__ __forceinline__ void stage_half(double* dst, const double* src, size_
 //  both bodies does not fit the 256 registers of two workgroups per CU)
 template <bool kFull>
 __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
-                                                  const double* const (&own)[4], int kb0, int kb1, int nlive, double* stage,
-                                                  int tid, int lane) {
+                                                  const double* const (&own)[4], int kb0, int kb1, int nlive, int nsub,
+                                                  double* stage, int tid, int lane) {
     if (kb0 >= kb1) return;
     const int r = lane & 15, g = lane >> 4;
     stage_half(stage, shared + (size_t)kb0 * T, lds_ld, tid, 0);
@@ -386,15 +390,16 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
         double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
         const int kn = (kb + 1 < kb1 ? kb + 1 : kb0) * T;  // refills past the end re-read the first block and are dropped
+        // (sub-blocks at or beyond nsub are the zero padding of the last 64-block: nothing to accumulate)
         mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
         load_rows(f0, own, kb * T + 32);
         stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 0);
-        mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
+        if (4 * kb + 1 < nsub) mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
         load_rows(f1, own, kb * T + 48);
-        mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
+        if (4 * kb + 2 < nsub) mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
         load_rows(f0, own, kn);
         stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 1);
-        mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
+        if (4 * kb + 3 < nsub) mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
         load_rows(f1, own, kn + 16);
         __syncthreads();
     }
@@ -553,6 +558,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
         // Tiles of block column j, four per pass, starting at the diagonal tile; every wave takes strip `wave` (16 rows) of
         // each of them:
         //   T(i) = K[i][j] - sum_{k<j} L[i][k] L[j][k]^T;   L[j][j] = chol(T(j));   L[i][j]^T = Dinv_j * T(i)^T
+        const int mcap = min(4, (nrows - j * T + 15) / 16);  // real 16-row groups of row panel j
         for (int i0 = j; i0 < nb; i0 += 4) {
             const int ntile = min(4, nb - i0);
             // the identity padding of the last tile has nothing to accumulate (its rows of L are zero left of the diagonal)
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
                     for (int e = 0; e < 4; ++e) acc[m][n][e] = K[row0[n] + j * T + 16 * m + 4 * e + g];
             // (first live block passed as a run-time value: with a literal hipcc merges the four sub-blocks of the panel loop
             //  into one basic block and then shuffles 160 accumulator registers between AGPRs and VGPRs per iteration)
-            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, (p.nb_max < 0) - 3, cap, stage, tid, lane);
+            panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, (p.nb_max < 0) - 3, cap, mcap, stage, tid, lane);
             const bool first = i0 == j;
             if (first) {
                 // strip 0 of every wave is its quarter of the diagonal tile
@@ -659,6 +665,7 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
                 for (int k = 0; k < T; ++k) t = fma(X[k * LD + tid], wc[o * T + rhs_slot(k)], t);
                 st_l2(rhs + (size_t)o * p.nmax + c * T + tid, t);
             }
+        const int mcap = min(4, (nrows - c * T + 15) / 16);  // real 16-row groups of row panel c of L (the rest: identity padding)
         for (int a0 = 0; a0 < c; a0 += 4) {
             // tiles a0 .. a0+3 of column c, strip `wave` of each: tile a0+n joins at block a0+n (U[a][k] = 0 for k < a, and
             // that part of U is not even written), so the four waves carry the same load through the pass's triangle
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(256) void gp_trtri_cols(const GpParams p) {
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
-            panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a0, ntile, stage, tid, lane);
+            panel_gemm_t(acc, L + (size_t)(c * T) * ld, ld, own, a0, c, a0, ntile, mcap, stage, tid, lane);
             double part[4][4] = {};
             left_mul_lds(X, acc, r, g, [&](int m, const v4d (&row)[4]) {
 #pragma unroll
@@ -747,10 +754,12 @@ __global__ __launch_bounds__(256, 2) void gp_kinv_trace(const GpParams p, double
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) acc[m][nn] = v4d{0.0, 0.0, 0.0, 0.0};
+    // contraction columns >= n are padding: rows < n of U are zero there (the padded rows are only wanted when K^-1 is stored)
+    const int nsub = kinv_out ? 4 * nb : (n + 15) / 16;
     if (ntile == 4)
-        panel_gemm_t_lean<true>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, 4, stage, tid, lane);
+        panel_gemm_t_lean<true>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, 4, nsub, stage, tid, lane);
     else
-        panel_gemm_t_lean<false>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, ntile, stage, tid, lane);
+        panel_gemm_t_lean<false>(acc, U + (size_t)(ta * T) * ld, ld, own, ta, nb, ntile, nsub, stage, tid, lane);
     // acc[m][nn][e] = -Kinv[gr][gc], gr = ta*64 + 16 m + 4 e + g (shared rows), gc = (tb0+nn)*64 + 16 wave + r (own rows)
     const double c = exp(p.theta[b * 3 + 0]), inv_l = exp(-p.theta[b * 3 + 1]);
     const double* x = p.x + (size_t)b * p.nmax;
