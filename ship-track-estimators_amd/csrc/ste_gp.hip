@@ -483,6 +483,9 @@ __device__ __forceinline__ void rhs_apply(double* rhs, size_t pitch, const doubl
 // (column-by-column with three barriers per column, then a 64-thread substitution) took ~250 us per block.
 // In:  S = the symmetric block (row-major, leading dimension LD).  Out: S = L (lower triangle, upper part zeroed),
 // X = L^-1 (lower triangular, zeros above).  `work` is a 64 x LDB scratch area.  *ok is cleared on a non-positive pivot.
+// (kCaller: one copy per calling kernel -- with a single call site the out-of-line function gets registers the caller is
+//  not using; shared between two kernels it follows the general convention and the caller spills 400 bytes around it)
+template <int kCaller>
 __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work, int lane, int* ok) {
     double a[T];
 #pragma unroll
@@ -530,6 +533,9 @@ __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work,
     for (int c = 0; c < T; ++c) X[c * LD + lane] = x[c];  // x[c] of lane `lane` = X[row c][column lane]
 }
 
+// kBuild: K is not read but evaluated where gp_kbuild would have put it (same expression, same bits), so that an
+// objective evaluation neither writes nor re-reads the 16 MB of K; the stand-alone ste_gp_potrf_f64 factors what is there.
+template <bool kBuild>
 __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
     __shared__ double S[T * LD];
     __shared__ double X[T * LD];
@@ -573,12 +579,51 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
             // acc[m][n][e] is element (jj = 16 m + 4 e + g, row r of strip n) of the transposed tiles; it starts as K[i][j]^T
             // (loads in flight behind the first panel blocks) and the negated panel products are accumulated onto it
             v4d acc[4][4];
+            if (kBuild) {
+                // (theta and x are re-read per pass: nothing of this is live across the panel loop)
+                const double* xb = p.x + (size_t)b * p.nmax;
+                const double kc = exp(p.theta[b * 3 + 0]), kinv_l = exp(-p.theta[b * 3 + 1]), ks = exp(p.theta[b * 3 + 2]);
+                double xc[4][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = j * T + 16 * m + 4 * e + g;
+                        xc[m][e] = col < nrows ? xb[col] : 0.0;
+                    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][n][e] = K[row0[n] + j * T + 16 * m + 4 * e + g];
+                for (int n = 0; n < 4; ++n) {
+                    const int row = min(i0 + n, nb - 1) * T + 16 * wave + r;
+                    const double xr = row < nrows ? xb[row] : 0.0;
+                    if (n < ntile) {  // (uniform: the strips of tiles the pass lacks are never stored)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int col = j * T + 16 * m + 4 * e + g;
+                                double v;
+                                if (row < nrows && col < nrows) {
+                                    const double d = (xr - xc[m][e]) * kinv_l;
+                                    v = kc * exp(-0.5 * d * d);
+                                    if (row == col) v += ks + p.jitter;
+                                } else {
+                                    v = (row == col) ? 1.0 : 0.0;
+                                }
+                                acc[m][n][e] = v;
+                            }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) acc[m][n] = v4d{0.0, 0.0, 0.0, 0.0};
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[m][n][e] = K[row0[n] + j * T + 16 * m + 4 * e + g];
+            }
             // (first live block passed as a run-time value: with a literal hipcc merges the four sub-blocks of the panel loop
             //  into one basic block and then shuffles 160 accumulator registers between AGPRs and VGPRs per iteration)
             panel_gemm_t(acc, K + (size_t)(j * T) * ld, ld, own, 0, j, (p.nb_max < 0) - 3, cap, mcap, stage, tid, lane);
@@ -591,7 +636,7 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
                     for (int e = 0; e < 4; ++e) S[(16 * wave + r) * LD + 16 * m + 4 * e + g] = acc[m][0][e];
                 __syncthreads();
                 if (wave == 0) {
-                    chol_trinv_wave(S, X, stage, lane, &ok);
+                    chol_trinv_wave<kBuild ? 1 : 0>(S, X, stage, lane, &ok);
                     for (int o = 0; o < nout; ++o) {
                         const int row = j * T + lane;
                         const double sj = row < nrows ? ld_l2(rhs + (size_t)o * p.nmax + row) : 0.0;
@@ -1158,7 +1203,7 @@ int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream) {
     stegp::GpParams p;
     int rc = gp_params(b, &p);
     if (rc) return rc;
-    hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(stegp::gp_potrf_cols<false>, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
     return gp_hip(hipGetLastError(), "gp_potrf launch");
 }
 
@@ -1175,8 +1220,8 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     const unsigned ns = (unsigned)p.nslots;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = p.nb_max * (p.nb_max + 1) / 2;
-    hipLaunchKernelGGL(stegp::gp_kbuild, dim3(tiles, ns), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(stegp::gp_potrf_cols, dim3(ns), dim3(256), 0, s, p);
+    // (no gp_kbuild: the factorisation evaluates the kernel function where it would read K)
+    hipLaunchKernelGGL(stegp::gp_potrf_cols<true>, dim3(ns), dim3(256), 0, s, p);
     // which of the two inverse kernels runs is a property of the batch (gp_params), never of this launch: a subset launch
     // must leave the bits a full launch leaves (include/ste.h: "per-matrix results do not depend on which other matrices are
     // listed"), and the two kernels sum in different orders
