@@ -32,7 +32,7 @@ ms = {}
 if stats:
     shutil.copy(stats[0], f"profiles/{RN}_gp_kernel_stats_1000x2000.csv")
     for r in csv.DictReader(open(stats[0])):
-        ms[r["Name"].split("(")[0]] = float(r["AverageNs"]) * 1e-6
+        ms[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"]) * 1e-6
 with open(f"profiles/{RN}_gp_counters_1000x2000.csv", "w") as f:
     f.write("# rocprofv3 --pmc <group> --kernel-trace -- python3 bench_gp.py --tracks 1000 --nobs 2000 --evals 2 --cpu-evals 0 (profiles/tools/pmc_passes_gp.sh);\n")
     f.write(f"# GP kernels of round {RN}; averages per launch; avg_ms from the --stats pass of the same script (no counters).\n")
