@@ -241,8 +241,9 @@ def measure_config3(dev, reps: int = 3):
             "seconds": secs, "track_steps": hb.track_steps, "value": hb.track_steps / secs, "unit": "track-steps/s",
             "prep_seconds_device": t_prep,
             "tracks_flagged_nan_or_index": int(((status | (hb.host_status if hb.host_status is not None else 0)) & 0x11 != 0).sum()),
-            "note": "7 tracks = 7 quads of one wave on one SIMD: a latency chain of ~19 000 sequential steps (about "
-                    f"{secs / max(int(hb.nsteps.max()), 1) * 1e6:.1f} us per step), not a throughput figure; five of the seven ships carry "
+            "note": "7 tracks = one quad per wave on 7 SIMDs: a latency chain of ~17 000 sequential steps (about "
+                    f"{secs / max(int(hb.nsteps.max()), 1) * 1e6:.1f} us per step of the longest track, forward + smoother), not a "
+                    "throughput figure; five of the seven ships carry "
                     "duplicate timestamps and end non-finite exactly where the reference raises LinAlgError"}
 
 
