@@ -89,7 +89,9 @@ typedef struct ste_ukf_batch_f64 {
                        to singular).  Bits 9 / 10 (0x200 / 0x400): ste_urtss_backward_f64 in its two-kernel / one-kernel form
                        whatever the batch size (default: two kernels -- all gains at once, then a lean recurrence -- up to 4 096
                        tracks, where the smoother is a few waves running a latency chain; one kernel above; same bits either way).
-                       Must not change between the backward calls made on one forward result.  Other bits are ignored */
+                       Bit 11 (0x800): the lean recurrence of the two-kernel form with a lane per track instead of a DPP quad per
+                       track (same bits; measurements).  Must not change between the backward calls made on one forward result.
+                       Other bits are ignored */
 
     /* sigma-fan constants, computed by the host exactly as unscented.py:95,125,132 does (HOST values) */
     double fan_scale; /* n / (1 - W0) */

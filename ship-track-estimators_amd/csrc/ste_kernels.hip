@@ -1850,6 +1850,165 @@ __global__ __launch_bounds__(64) void urtss_recur_lean(const KParams p) {
     if (!(chk == 0.0)) atomicOr(&p.status[t], STE_STATUS_NAN);
 }
 
+// The lean recurrence with ONE DPP QUAD PER TRACK.  A block of a few tracks runs urtss_recur_lean at the pace at which one
+// wave issues its ~450 instructions per step (44 loads and 16-22 stores with their 64-bit address arithmetic, ~180 fp64
+// operations): 1.3 us per step on configs[3], and neither deeper prefetch nor a run-ahead wave warming L2 nor plain instead
+// of nontemporal stores moved it -- it is issue, not latency.  Here lane q of a quad owns row q: K[q][:], x[q], and the part
+// (q, c >= q) of the packed covariances; y and dP are broadcast through the quad, the K rows of the lanes to the right come
+// by quad rotation: ~60 fp64 operations, 52 DPP moves, 14 loads and <= 9 stores per lane and step.  Every element is
+// computed by exactly one lane with urtss_recur_lean's sequence of operations: same bits (tests/test_fleet.py).
+struct LeanRowQ {
+    double K[4], xb, xk, Pb[4], Pk[4];  // row q of K; element q of x_b and x_k; slot j = element (q, q + j) of P_b and P_k
+};
+__device__ __forceinline__ int pidx(int r, int c) { return r * 4 - (r * (r - 1)) / 2 + (c - r); }  // tix for r <= c at run time
+__device__ __forceinline__ void load_lean_row_q(const KParams& p, size_t k, size_t B, size_t t, int q, bool packed, LeanRowQ& g) {
+    const double* w = p.rts_work + (k * kWorkElems) * B + t;
+    g.K[0] = w[(size_t)(kLeanK01 + 2 * q + 0) * B];
+    g.K[1] = w[(size_t)(kLeanK01 + 2 * q + 1) * B];
+    g.K[2] = w[(size_t)(kLeanK23 + 2 * q + 0) * B];
+    g.K[3] = w[(size_t)(kLeanK23 + 2 * q + 1) * B];
+    g.xb = w[(size_t)(kWorkXb + q) * B];
+    g.xk = p.fwd_mean[(k * 4 + (size_t)q) * B + t];
+    STE_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const int c = min(q + j, 3);  // slots past the row's end repeat its last element and are never used
+        g.Pb[j] = w[(size_t)(kWorkPb + pidx(q, c)) * B];
+        g.Pk[j] = p.fwd_cov[(packed ? k * 10 + (size_t)pidx(q, c) : k * 16 + (size_t)(q * 4 + c)) * B + t];
+    }
+}
+// x[q], P(q, q + j) -> history row `row` (both triangles of the full layout: the lane that computed (r, c) also stores (c, r))
+__device__ __forceinline__ void store_lean_row_q(const KParams& p, size_t row, size_t B, size_t t, int q, bool packed, double x,
+                                                 const double (&P)[4]) {
+    st_stream(&p.sm_mean[(row * 4 + (size_t)q) * B + t], x);
+    if (p.sm_pos && q < 2) st_stream(&p.sm_pos[(row * 2 + (size_t)q) * B + t], x);
+    STE_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const int c = q + j;
+        if (c < 4) {
+            if (packed) {
+                st_stream(&p.sm_cov[(row * 10 + (size_t)pidx(q, c)) * B + t], P[j]);
+            } else {
+                st_stream(&p.sm_cov[(row * 16 + (size_t)(q * 4 + c)) * B + t], P[j]);
+                if (j) st_stream(&p.sm_cov[(row * 16 + (size_t)(c * 4 + q)) * B + t], P[j]);
+            }
+        }
+    }
+}
+// value held by lane (q + J) mod 4 of the quad
+template <int J>
+__device__ __forceinline__ double quad_rot(double v) {
+    static_assert(J >= 1 && J <= 3, "quad rotation");
+    return dpp_move<(J == 1) ? 0x39 : (J == 2) ? 0x4E : 0x93>(v);  // quad_perm [1,2,3,0] / [2,3,0,1] / [3,0,1,2]
+}
+
+__global__ __launch_bounds__(64) void urtss_recur_lean_q4(const KParams p) {
+    const size_t B = (size_t)p.ld;
+    const int q = threadIdx.x & 3;
+    const size_t t = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+    if (t >= (size_t)p.B) return;  // whole quads leave
+    const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
+    const bool packed = (p.flags & STE_FLAG_PACKED_COV) != 0;
+    const int last_row = p.Nmax > 0 ? p.Nmax - 1 : 0;
+    if (q == 0) {
+        const double fb = p.first_bad[t];
+        if (fb >= 0.0) p.first_bad[t] = -fb - 1.0;  // the work rows of this track hold gains from here on (urtss_recur_lean)
+    }
+    double xs, Ps[4];  // x^s[q]; slot j = P^s(q, q + j)
+    xs = p.fwd_mean[((size_t)ns * 4 + (size_t)q) * B + t];
+    STE_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const int c = min(q + j, 3);
+        Ps[j] = p.fwd_cov[(packed ? (size_t)ns * 10 + (size_t)pidx(q, c) : (size_t)ns * 16 + (size_t)(q * 4 + c)) * B + t];
+    }
+    store_lean_row_q(p, (size_t)ns, B, t, q, packed, xs, Ps);
+    LeanRowQ nxt;
+    if (ns > 0) load_lean_row_q(p, (size_t)(ns - 1), B, t, q, packed, nxt);
+    for (int k = p.Nmax - 1; k >= 0; --k) {
+        if (!__any(k < ns)) continue;
+        if (k < ns) {
+            const LeanRowQ cur = nxt;
+            load_lean_row_q(p, (size_t)min(max(k - 1, 0), last_row), B, t, q, packed, nxt);  // in flight during this step
+            // y = x^s_{k+1} - x_b, the course difference wrapped (lane 3's element)
+            double yq = xs - cur.xb;
+            {
+                const double yw = wrap180(yq);
+                yq = (q == 3) ? yw : yq;
+            }
+            const double y0 = bcast<0>(yq), y1 = bcast<1>(yq), y2 = bcast<2>(yq), y3 = bcast<3>(yq);
+            double acc = cur.xk;
+            acc = fma(cur.K[0], y0, acc);
+            acc = fma(cur.K[1], y1, acc);
+            acc = fma(cur.K[2], y2, acc);
+            acc = fma(cur.K[3], y3, acc);
+            {
+                const double am = floored_mod(acc, 360.0);
+                xs = (q == 3) ? am : acc;
+            }
+            // dP = P^s_{k+1} - P_b on the owner of each element, then the whole symmetric matrix to every lane of the quad
+            double d[4];
+            STE_UNROLL
+            for (int j = 0; j < 4; ++j) d[j] = Ps[j] - cur.Pb[j];
+            double dP[10];
+            dP[tix(0, 0)] = bcast<0>(d[0]);
+            dP[tix(0, 1)] = bcast<0>(d[1]);
+            dP[tix(0, 2)] = bcast<0>(d[2]);
+            dP[tix(0, 3)] = bcast<0>(d[3]);
+            dP[tix(1, 1)] = bcast<1>(d[0]);
+            dP[tix(1, 2)] = bcast<1>(d[1]);
+            dP[tix(1, 3)] = bcast<1>(d[2]);
+            dP[tix(2, 2)] = bcast<2>(d[0]);
+            dP[tix(2, 3)] = bcast<2>(d[1]);
+            dP[tix(3, 3)] = bcast<3>(d[0]);
+            // row q of K dP
+            double KdP[4];
+            STE_UNROLL
+            for (int c = 0; c < 4; ++c) {
+                double a2 = cur.K[0] * dP[tix(0, c)];
+                STE_UNROLL
+                for (int i = 1; i < 4; ++i) a2 = fma(cur.K[i], dP[tix(i, c)], a2);
+                KdP[c] = a2;
+            }
+            // P^s(q, q + j) = P_k(q, q + j) + sum_i KdP[q][i] K[q + j][i]: the K row of the lane j places to the right
+            {
+                double a2 = KdP[0] * cur.K[0];
+                STE_UNROLL
+                for (int i = 1; i < 4; ++i) a2 = fma(KdP[i], cur.K[i], a2);
+                Ps[0] = cur.Pk[0] + a2;
+            }
+            {
+                const double k0 = quad_rot<1>(cur.K[0]), k1 = quad_rot<1>(cur.K[1]), k2 = quad_rot<1>(cur.K[2]), k3 = quad_rot<1>(cur.K[3]);
+                double a2 = KdP[0] * k0;
+                a2 = fma(KdP[1], k1, a2);
+                a2 = fma(KdP[2], k2, a2);
+                a2 = fma(KdP[3], k3, a2);
+                Ps[1] = cur.Pk[1] + a2;
+            }
+            {
+                const double k0 = quad_rot<2>(cur.K[0]), k1 = quad_rot<2>(cur.K[1]), k2 = quad_rot<2>(cur.K[2]), k3 = quad_rot<2>(cur.K[3]);
+                double a2 = KdP[0] * k0;
+                a2 = fma(KdP[1], k1, a2);
+                a2 = fma(KdP[2], k2, a2);
+                a2 = fma(KdP[3], k3, a2);
+                Ps[2] = cur.Pk[2] + a2;
+            }
+            {
+                const double k0 = quad_rot<3>(cur.K[0]), k1 = quad_rot<3>(cur.K[1]), k2 = quad_rot<3>(cur.K[2]), k3 = quad_rot<3>(cur.K[3]);
+                double a2 = KdP[0] * k0;
+                a2 = fma(KdP[1], k1, a2);
+                a2 = fma(KdP[2], k2, a2);
+                a2 = fma(KdP[3], k3, a2);
+                Ps[3] = cur.Pk[3] + a2;
+            }
+            store_lean_row_q(p, (size_t)k, B, t, q, packed, xs, Ps);
+        }
+    }
+    double chk = xs * 0.0;
+    STE_UNROLL
+    for (int j = 0; j < 4; ++j)
+        if (q + j < 4) chk += Ps[j] * 0.0;
+    if (!(chk == 0.0)) atomicOr(&p.status[t], STE_STATUS_NAN);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // single-function kernels (fine-grained API parity: geodetic_dynamics, compute_sigma_points)
 // ---------------------------------------------------------------------------------------------------------------
@@ -2200,7 +2359,11 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
             hipLaunchKernelGGL(ste::urtss_gains_all<false>, dim3(ggrid), dim3(64), 0, s, kp);
         int rc = check_hip(hipGetLastError(), "urtss_gains_all launch");
         if (rc) return rc;
-        hipLaunchKernelGGL(ste::urtss_recur_lean, dim3(grid), dim3(64), 0, s, kp);
+        // the recurrence: a quad per track (16 tracks per wave); tuning bit 11 (0x800) keeps the lane-per-track form
+        if (kp.tuning & 0x800)
+            hipLaunchKernelGGL(ste::urtss_recur_lean, dim3(grid), dim3(64), 0, s, kp);
+        else
+            hipLaunchKernelGGL(ste::urtss_recur_lean_q4, dim3((unsigned)((kp.B + 15) / 16)), dim3(64), 0, s, kp);
         return check_hip(hipGetLastError(), "urtss_recur_lean launch");
     }
     if (kp.rts_work) {

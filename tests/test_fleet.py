@@ -266,20 +266,21 @@ def test_two_kernel_smoother_is_the_one_kernel_smoother_bit_for_bit(kind):
         hb.P0 = np.ascontiguousarray(P0.reshape(hb.B, 16).T)
         tun = 0x100
     outs = {}
-    for form in (0x400, 0x200):
+    for form in (0x400, 0x200, 0x200 | 0x800):  # one kernel; gains + quad-per-track recurrence; gains + lane-per-track recurrence
         db = batch.DeviceBatch(hb, tuning=tun | form, sm_pos=True)
         _zero_outputs(db)
         db.run()
         torch.cuda.synchronize()
         outs[form] = [t.clone() for t in (db.sm_mean, db.sm_cov, db.sm_pos, db.status, db.fwd_mean)]
-        if form == 0x200:
+        if form & 0x200:
             db.sm_mean.zero_()
             db.backward()  # again, on work rows that now hold gains
             torch.cuda.synchronize()
             assert torch.equal(db.sm_mean, outs[form][0])
             assert bool((db.rts_work[-1] < 0).all())  # the marker: first-bad word stored negated
-    for a, b in zip(outs[0x400], outs[0x200]):
-        assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))
+    for form in (0x200, 0x200 | 0x800):
+        for a, b in zip(outs[0x400], outs[form]):
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-1.0), torch.nan_to_num(b.double(), nan=-1.0))
 
 
 def test_run_fleet_forward_only_and_selected_outputs():
