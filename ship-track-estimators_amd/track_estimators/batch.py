@@ -173,8 +173,8 @@ STATUS_HOST_INDEX = binding.STE_STATUS_HOST_INDEX  # the reference would raise I
 # A per-call flag of the C ABI underneath (STE_FLAG_LANES_1 / _4); the tests set this to run every case in both mappings.
 default_lanes = 0
 # ste_ukf_batch_f64.tuning of batches that do not name one (DeviceBatch(tuning=0)).  Bits (include/ste.h): 0x100 every smoother
-# gain by the eigenvalue route, 0x200 / 0x400 the two-kernel / one-kernel smoother whatever the batch size, 0x800 the two-kernel form's recurrence with a lane
-# instead of a quad per track.  Tests set it.
+# gain by the eigenvalue route, 0x200 / 0x400 the two-kernel / one-kernel smoother whatever the batch size, 0x800 the
+# two-kernel form's recurrence with a lane instead of a quad per track.  Tests set it.
 default_tuning = 0
 
 
