@@ -364,13 +364,24 @@ __device__ __forceinline__ void mma_sub_lean(v4d (&acc)[4][4], const double* blk
             }
     }
 }
-__device__ __forceinline__ void stage_half(double* dst, const double* src, size_t ld, int tid, int half) {
+__device__ __forceinline__ void stage_half_load(v4d (&st)[2], const double* src, size_t ld, int tid, int half) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 256 * (2 * half + q);
-        const v4d v = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 4);
-        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -v;
+        st[q] = *reinterpret_cast<const v4d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 4);
     }
+}
+__device__ __forceinline__ void stage_half_store(double* dst, const v4d (&st)[2], int tid, int half) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 256 * (2 * half + q);
+        *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -st[q];
+    }
+}
+__device__ __forceinline__ void stage_half(double* dst, const double* src, size_t ld, int tid, int half) {
+    v4d st[2];
+    stage_half_load(st, src, ld, tid, half);
+    stage_half_store(dst, st, tid, half);
 }
 // (nlive is fixed for the pass here; kFull = all four strips live: the two cases are separate loops, because one loop with
 //  both bodies does not fit the 256 registers of two workgroups per CU)
@@ -391,14 +402,19 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
         double* nxt = stage + (((kb - kb0) & 1) ^ 1) * (T * LDB);
         const int kn = (kb + 1 < kb1 ? kb + 1 : kb0) * T;  // refills past the end re-read the first block and are dropped
         // (sub-blocks at or beyond nsub are the zero padding of the last 64-block: nothing to accumulate)
+        // each half of the next panel block is fetched one sub-block before it is parked in LDS: fetched and parked in one go,
+        // the wave sat through a whole memory latency twice per block (s_waitcnt vmcnt(0) right behind the loads)
+        v4d st[2];
+        stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
         mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
         load_rows(f0, own, kb * T + 32);
-        stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 0);
+        stage_half_store(nxt, st, tid, 0);
+        stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 1);
         if (4 * kb + 1 < nsub) mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
         load_rows(f1, own, kb * T + 48);
         if (4 * kb + 2 < nsub) mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
         load_rows(f0, own, kn);
-        stage_half(nxt, shared + (size_t)kn, lds_ld, tid, 1);
+        stage_half_store(nxt, st, tid, 1);
         if (4 * kb + 3 < nsub) mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
         load_rows(f1, own, kn + 16);
         __syncthreads();
