@@ -475,19 +475,35 @@ __device__ __forceinline__ void rhs_accumulate(double (&part)[4][4], const v4d (
 // wave lies in the pass's n-th tile); rows >= nrows do not exist
 __device__ __forceinline__ void rhs_apply(double* rhs, size_t pitch, const double (&part)[4][4], int base, int r, int g,
                                           int nrows, int nout, double sign, int n0, int n1) {
+    // three phases -- reduce, load everything, store everything -- so that the L2 round trips of the sixteen
+    // read-modify-writes overlap instead of queueing behind one s_waitcnt vmcnt(0) each
+    double t[4][4], old[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            double v = part[o][n];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            t[o][n] = v;
+            old[o][n] = 0.0;
+        }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
         if (o < nout) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                double t = part[o][n];
-                t += __shfl_xor(t, 16);
-                t += __shfl_xor(t, 32);
                 const int idx = base + T * n + r;
-                if (g == 0 && n >= n0 && n < n1 && idx < nrows) {
-                    double* q = rhs + (size_t)o * pitch + idx;
-                    st_l2(q, fma(sign, t, ld_l2(q)));
-                }
+                if (g == 0 && n >= n0 && n < n1 && idx < nrows) old[o][n] = ld_l2(rhs + (size_t)o * pitch + idx);
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < nout) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int idx = base + T * n + r;
+                if (g == 0 && n >= n0 && n < n1 && idx < nrows) st_l2(rhs + (size_t)o * pitch + idx, fma(sign, t[o][n], old[o][n]));
             }
         }
 }
