@@ -269,11 +269,14 @@ typedef struct ste_gp_batch_f64 {
     const double* x;     /* [B][nmax] */
     const double* y;     /* [B][nout][nmax] */
     const double* theta; /* [B][3] log(constant), log(length_scale), log(noise) */
-    double* K;      /* [B][ld][ld]  K(X,X) + (noise + jitter) I, then its Cholesky factor L (lower triangle) */
+    double* K;      /* [B][ld][ld]  K(X,X) + (noise + jitter) I (ste_gp_rbf_kmatrix_f64), then its Cholesky factor L (lower triangle,
+                       diagonal included; what is above the diagonal is not defined).  ste_gp_lml_f64 evaluates the kernel
+                       function inside the factorisation and leaves L here without K ever being stored */
     double* U;      /* [B][ld][ld]  workspace: L^-T (upper triangle) */
     double* Dinv;   /* [B][(ld-16)/64][64][64] workspace: inverses of the diagonal blocks of L */
     double* Kinv;   /* [B][ld][ld] K^-1 (both triangles) when non-NULL; needed by ste_gp_predict_f64 */
-    double* alpha;  /* [B][nout][nmax] out: K^-1 y */
+    double* alpha;  /* [B][nout][nmax] out: K^-1 y (after ste_gp_potrf_f64 alone: the forward substitution L^-1 y, which rides along
+                       with the factorisation) */
     double* lml;    /* [B] out: log marginal likelihood summed over outputs */
     double* grad;   /* [B][3] out: d lml / d theta, or NULL to skip the gradient */
     double* tr;     /* [B][3][nt] workspace, nt = nb(nb + 1)/2 with nb = ceil(nmax/64): per-tile partial traces (summed in tile order) */
@@ -285,13 +288,14 @@ const char* ste_gp_last_error(void);
 /* K(X,X) build only (lower 64x64 tiles + identity padding) -- sklearn kernel __call__ (RBF: exp(-pdist^2/2)). */
 int ste_gp_rbf_kmatrix_f64(const ste_gp_batch_f64* b, void* stream);
 
-/* In-place blocked Cholesky of K (scipy.linalg.cholesky(K, lower=True) in GaussianProcessRegressor). */
+/* In-place blocked Cholesky of the K that ste_gp_rbf_kmatrix_f64 left in the buffer (scipy.linalg.cholesky(K, lower=True) in
+ * GaussianProcessRegressor); also writes L^-1 y to alpha and the inverted diagonal blocks to Dinv. */
 int ste_gp_potrf_f64(const ste_gp_batch_f64* b, void* stream);
 
 /*
  * One objective evaluation per track (GaussianProcessRegressor.log_marginal_likelihood(theta, eval_gradient=True)):
- * K build, Cholesky, L^-T, alpha, lml, and -- when grad != NULL -- the gradient via K^-1 = L^-T L^-1 reduced against
- * dK/dtheta on the fly.
+ * Cholesky of K (the kernel function evaluated in place of a stored K; same values as ste_gp_rbf_kmatrix_f64), L^-T, alpha,
+ * lml, and -- when grad != NULL -- the gradient via K^-1 = L^-T L^-1 reduced against dK/dtheta on the fly.
  */
 int ste_gp_lml_f64(const ste_gp_batch_f64* b, void* stream);
 
