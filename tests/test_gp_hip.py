@@ -36,6 +36,34 @@ def test_kmatrix_and_cholesky_vs_oracle():
         np.testing.assert_allclose(L[b, :n, :n], Lref, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("order", [1, 2], ids=["row-ordered-inverse", "column-ordered-inverse"])
+def test_objective_factors_the_kernel_function_in_place_with_the_stand_alone_bits(order):
+    """``ste_gp_lml_f64`` never stores K: the factorisation evaluates the kernel function where ``ste_gp_potrf_f64`` reads the
+    matrix ``ste_gp_rbf_kmatrix_f64`` built.  Same expression, same blocked algorithm: the L it leaves is the stand-alone L bit
+    for bit; and the alpha that rides along with factorisation and inversion is K^-1 y."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    data = [_data(g, n) for n in NAMES]
+    th = g["thetas"][1]
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data], inverse_order=order)
+    thetas = np.tile(th, (3, 1))
+    batch.kmatrix(thetas)
+    L_alone, status = batch.cholesky()
+    assert not status.any()
+    _, _, status = batch.objective(thetas)
+    assert not status.any()
+    L_fused = np.tril(batch.t_K.cpu().numpy())
+    alpha = batch.alpha()
+    for b, (x, y) in enumerate(data):
+        n = len(x)
+        assert np.array_equal(L_fused[b, :n, :n], L_alone[b, :n, :n])
+        Kref, _ = gpo.kernel_matrix(th, x)
+        Kref[np.diag_indices_from(Kref)] += gpo.JITTER
+        np.testing.assert_allclose(alpha[b], np.linalg.solve(Kref, y), rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_lml_and_gradient_vs_reference(batched):
     """Ragged batch (n = 52, 130, 300 -> 1, 3, 5 tiles) at four thetas, vs scikit-learn through the reference wrapper."""
