@@ -64,6 +64,33 @@ def test_objective_factors_the_kernel_function_in_place_with_the_stand_alone_bit
         np.testing.assert_allclose(alpha[b], np.linalg.solve(Kref, y), rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("nout", [1, 3, 4])
+@pytest.mark.parametrize("order", [1, 2], ids=["row-ordered-inverse", "column-ordered-inverse"])
+def test_objective_with_one_to_four_outputs_vs_oracle(nout, order):
+    """The right-hand sides (w = L^-1 y inside the factorisation, alpha = U w inside the inversion) and the quadratic forms
+    (inside the K^-1 reduction) run over ``nout`` = 1..4 output columns; the reference only ever passes two (lon, lat)."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    rng = np.random.default_rng(nout)
+    data = []
+    for name in NAMES:
+        x, y2 = _data(g, name)
+        y = np.column_stack([y2, y2[:, ::-1] + 0.1 * rng.standard_normal(y2.shape)])[:, :nout]
+        data.append((x, np.ascontiguousarray(y)))
+    th = g["thetas"][2]
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data], inverse_order=order)
+    lml, grad, status = batch.objective(np.tile(th, (3, 1)))
+    assert not status.any()
+    alpha = batch.alpha()
+    for b, (x, y) in enumerate(data):
+        want_lml, want_grad, _, want_alpha = gpo.lml_and_grad(th, x, y)
+        assert np.isclose(lml[b], want_lml, rtol=1e-9, atol=1e-7)
+        np.testing.assert_allclose(grad[b], want_grad, rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(alpha[b], want_alpha, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_lml_and_gradient_vs_reference(batched):
     """Ragged batch (n = 52, 130, 300 -> 1, 3, 5 tiles) at four thetas, vs scikit-learn through the reference wrapper."""
