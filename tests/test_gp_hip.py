@@ -91,6 +91,29 @@ def test_objective_with_one_to_four_outputs_vs_oracle(nout, order):
         np.testing.assert_allclose(alpha[b], want_alpha, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("order", [1, 2], ids=["row-ordered-inverse", "column-ordered-inverse"])
+def test_objective_at_tile_boundaries_vs_oracle(order):
+    """n = 2, 16, 63, 64, 65, 128, 129, 192 in one ragged batch: whole tiles, one row over, one strip, almost nothing -- the
+    strip, padding and short-pass logic of the panel kernels at every boundary."""
+    from oracle import gp_oracle as gpo
+    from track_estimators.gaussian_processes.device import GpDeviceBatch
+
+    g = np.load(os.path.join(GOLDEN, "gp.npz"))
+    x_all, y_all = _data(g, "syn300")
+    sizes = [2, 16, 63, 64, 65, 128, 129, 192]
+    data = [(x_all[:n].copy(), np.ascontiguousarray(y_all[:n])) for n in sizes]
+    th = g["thetas"][1]
+    batch = GpDeviceBatch([d[0] for d in data], [d[1] for d in data], inverse_order=order)
+    lml, grad, status = batch.objective(np.tile(th, (len(sizes), 1)))
+    assert not status.any()
+    alpha = batch.alpha()
+    for b, (x, y) in enumerate(data):
+        want_lml, want_grad, _, want_alpha = gpo.lml_and_grad(th, x, y)
+        assert np.isclose(lml[b], want_lml, rtol=1e-9, atol=1e-7), sizes[b]
+        np.testing.assert_allclose(grad[b], want_grad, rtol=1e-6, atol=1e-5, err_msg=str(sizes[b]))
+        np.testing.assert_allclose(alpha[b], want_alpha, rtol=1e-6, atol=1e-8, err_msg=str(sizes[b]))
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_lml_and_gradient_vs_reference(batched):
     """Ragged batch (n = 52, 130, 300 -> 1, 3, 5 tiles) at four thetas, vs scikit-learn through the reference wrapper."""
