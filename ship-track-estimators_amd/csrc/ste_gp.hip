@@ -590,7 +590,6 @@ __global__ __launch_bounds__(256) void gp_potrf_cols(const GpParams p) {
     if (tid == 0) ok = 1;
     __threadfence_block();
     __syncthreads();
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
     const int r = lane & 15, g = lane >> 4;
     for (int j = 0; j < nb; ++j) {
         // Tiles of block column j, four per pass, starting at the diagonal tile; every wave takes strip `wave` (16 rows) of
@@ -1251,7 +1250,6 @@ static int gp_lml_launch(const ste_gp_batch_f64* b, int32_t count, const int32_t
     }
     const unsigned ns = (unsigned)p.nslots;
     hipStream_t s = (hipStream_t)stream;
-    const int tiles = p.nb_max * (p.nb_max + 1) / 2;
     // (no gp_kbuild: the factorisation evaluates the kernel function where it would read K)
     hipLaunchKernelGGL(stegp::gp_potrf_cols<true>, dim3(ns), dim3(256), 0, s, p);
     // which of the two inverse kernels runs is a property of the batch (gp_params), never of this launch: a subset launch
