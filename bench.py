@@ -14,17 +14,22 @@ Workload
           of the smoothed lon/lat.  Per-GPU work is fixed as N grows ("weak").
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel (forward filter): algorithmic HBM bytes per launch / its mean HIP-event duration vs
-                8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary under profiles/ (same
-                kernel generation, same command); `fp64_valu` = executed fp64 VALU work from the same summary, beside the
-                nominal SURVEY.md estimate (labelled)
-  cpu_baseline  the NumPy oracle ("port" of the reference arithmetic) timed on this box's host cores on a bounded sample
-                (one process, and one forked worker per core of the box's CPU share)
+  roofline      SURVEY.md section 8(d)'s figure: `achieved` = 512 algorithmic HBM bytes per track-step (192 forward + 320
+                smoother) x the track-steps per second of the timed region, per GPU, against 8 TB/s (the forward and smoother
+                kernels of different steps share the chip, so the path's rate is the job's rate); `traffic` = HBM bytes of one
+                step (one forward + one smoother launch) from the committed rocprofv3 PMC summary under profiles/ (same kernel
+                generation, same command); `per_launch` = one forward launch's 192 B per track-step over its own HIP-event
+                duration, with the launches in flight beside it; `fp64_valu` = executed fp64 VALU work from the same summary,
+                beside the nominal SURVEY.md estimate (labelled)
+  cpu_baseline  the NumPy oracle timed on this box's host cores on bounded samples of the same batch: the vectorised
+                restatement ("port"; one process, and one forked worker per core of the box's CPU share) and
+                `reference_call_sequence`, the per-track restatement that issues the reference's own calls in its order
   serial        one batch at a time, forward then smoother on one unrestricted stream -- the latency figure
 
 Steps are pipelined by default (track_estimators.batch.SmootherPipeline): every step runs the complete forward pass
-and smoother of one batch, but several steps are in flight -- forward passes on one CU partition, the smoothers of the
-steps before them on the rest, on CU-masked streams, with one set of history buffers per step in flight plus one.
+and smoother of one batch, but several steps are in flight -- forward passes and the smoothers of the steps before them
+share every compute unit (one forward wave per SIMD by construction, smoother waves beside them), each stream on a
+hardware queue of its own, with one set of history buffers per step in flight plus one.
 """
 import argparse
 import contextlib
@@ -96,6 +101,31 @@ def cpu_baseline(ntracks: int, seed0: int = 0):
     sm, sP = orc.backward_batch(m, P, Q, hb.dt.T, rr, sb.sog_rate, sb.cog_rate)
     dt = time.perf_counter() - t0
     return hb.track_steps / dt, dt, (m, P, sm, sP), hb
+
+
+def cpu_reference_call_sequence(ntracks: int, seed0: int = 0):
+    """Time the oracle's per-track restatement -- the one that issues the reference's own call sequence
+    (kalman_filter.py:61-117 and unscented.py:285-351: ``scipy.linalg.sqrtm`` per fan, a Python loop over the nine sigma
+    points, ``np.linalg.pinv`` per gain; bit-exact against the reference on every golden case, tests/test_oracle_golden.py)
+    -- on the first ``ntracks`` tracks of the bench batch, one track after the other like the loop of
+    examples/example_ukf_rts_smoother_batch.py:19-90.  One process, one core."""
+    from track_estimators import synthetic
+    from track_estimators.utils import generate_dts
+
+    from oracle import ukf_oracle as orc
+
+    H, Q, R, P0 = synthetic.example_matrices()
+    sb = synthetic.make_batch(ntracks, nobs=NOBS, gap_h=1.0, seed0=seed0)
+    steps, out = 0, []
+    t0 = time.perf_counter()
+    for b in range(ntracks):
+        dt = generate_dts(sb.dts[b], SUBSTEPS)
+        m, P = orc.forward_track(sb.z[b][:, 0], P0, H, Q, R, dt, sb.dts[b], sb.z[b], sb.sog_rate[b], sb.cog_rate[b])
+        sm, sP = orc.backward_track(m, P, Q, dt, len(sb.dts[b]), sb.sog_rate[b], sb.cog_rate[b])
+        steps += len(dt)
+        out.append((m, P, sm, sP))
+    secs = time.perf_counter() - t0
+    return steps / secs, secs, out
 
 
 def _pool_worker(job):
@@ -329,8 +359,15 @@ def _main(stack):
                          "BASELINE configs[1]; 12 500 x N otherwise = configs[2]'s shard size, 100 000 at --gpus 8)")
     ap.add_argument("--tracks", type=int, default=None, help="tracks per GPU (overrides --total-tracks; tests)")
     ap.add_argument("--cpu-tracks", type=int, default=3072, help="tracks in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-ref-tracks", type=int, default=8,
+                    help="tracks of the batch timed through the oracle's per-track form, the reference's own call sequence "
+                         "(about 0.4 s per 500-step track; 0 = skip)")
     ap.add_argument("--lanes", type=int, default=0, help="forward-kernel lanes per track (0 = by batch size, 1, 4)")
     ap.add_argument("--no-gather", action="store_true", help="skip the all-gather of smoothed lon/lat when N>1")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N>1: run the all-gather of the smoothed lon/lat once per this many steps (default 1 = BASELINE "
+                         "configs[2] as written, every step's batch is exchanged; K = --steps is one exchange per K-batch "
+                         "fleet, what a real 100 000-track job needs)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run forward and smoother of every step back to back on one stream instead of overlapping the "
                          "smoothers of earlier steps with the forward passes of later ones on disjoint CU partitions")
@@ -381,7 +418,7 @@ def _main(stack):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    dist = None
+    dist = nccl_log = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
 
@@ -390,6 +427,15 @@ def _main(stack):
         # STE_BENCH_BACKEND=gloo lets several ranks share one GPU for a rehearsal of the N>1 control flow (RCCL refuses
         # two ranks on one device); the driver's multi-GPU runs use the default, nccl = RCCL over xGMI.
         backend = os.environ.get("STE_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and os.environ.get("STE_BENCH_KEEP_NCCL_ENV") != "1":
+            # which algorithm / protocol RCCL picks for the exchange: its TUNING log lines, into a file per rank (stdout
+            # carries the one JSON line), read back after the untimed all_gather_alone leg.  A caller's own NCCL_DEBUG settings
+            # are replaced for this process (STE_BENCH_KEEP_NCCL_ENV=1 keeps them and drops the `rccl` object)
+            import tempfile
+
+            nccl_log = os.path.join(tempfile.gettempdir(), f"ste_bench_rccl_{os.getpid()}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="TUNING,COLL", NCCL_DEBUG_FILE=nccl_log)
+            stack.callback(lambda: os.path.exists(nccl_log) and os.unlink(nccl_log))
         ndev = torch.cuda.device_count()
         local_rank = local_rank % max(ndev, 1)
         if backend == "nccl":
@@ -444,7 +490,7 @@ def _main(stack):
     stream = torch.cuda.current_stream(dev)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
 
-    def serial_step(d, events=None):
+    def serial_step(d, events=None, exchange=True):
         if events is not None:
             events[0].record(stream)
         d.forward(stream)
@@ -454,17 +500,21 @@ def _main(stack):
         d.backward(stream)
         if events is not None:
             events[3].record(stream)
-        if gathered is not None:
+        if gathered is not None and exchange:
             gathered.launch(d.sm_pos)
+
+    if args.gather_every < 1:
+        raise SystemExit("--gather-every must be >= 1")
 
     def one_step(k, events=None, final=False):
         d = dbs[k % len(dbs)]
+        exchange = gathered is not None and (k + 1) % args.gather_every == 0
         if pipe is None:
-            serial_step(d, events)
+            serial_step(d, events, exchange)
         else:
             # the exchange sends the smoother's own output (sm_pos): no snapshot; the event it returns keeps the next use of
             # this buffer set behind the collective that reads it
-            pipe.submit(d, after_smoother=(lambda _s: gathered.launch_for_pipeline(d.sm_pos)) if gathered is not None else None,
+            pipe.submit(d, after_smoother=(lambda _s: gathered.launch_for_pipeline(d.sm_pos)) if exchange else None,
                         timing=events, final=final)
 
     def drain():
@@ -542,6 +592,21 @@ def _main(stack):
                                 "rank to every rank) with no kernels beside it, blocking, slowest rank; in the timed region "
                                 "it is asynchronous and double-buffered under the following steps"}
 
+    rccl_choice = None
+    if gather_alone is not None and nccl_log is not None and rank == 0:
+        # RCCL's own words about the collective it just ran (TUNING: "... Bytes -> Algo ... proto ..."; COLL: the call)
+        try:
+            with open(nccl_log, errors="replace") as f:
+                lines = [ln.strip() for ln in f if "AllGather" in ln or "Algo" in ln]
+            tun = [ln.split("NCCL INFO", 1)[-1].strip() for ln in lines if "Algo" in ln]
+            rccl_choice = {"tuning_lines": sorted(set(tun))[-4:] or None, "allgather_calls_logged": sum("AllGather" in ln for ln in lines),
+                           "note": "NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=TUNING,COLL of this process, rank 0 (a communicator of one "
+                                   "rank copies locally and logs no algorithm)"}
+        except OSError as exc:
+            rccl_choice = {"error": str(exc)}
+    if gather_alone is not None:
+        gather_alone["rccl"] = rccl_choice
+
     # The same timed loop with the exchange switched off (not the timed region): one run then reads as filter against
     # exchange -- `value` has the gather in every step, `filter_only` does not, `all_gather_alone` is the gather by itself.
     filter_only = None
@@ -556,10 +621,13 @@ def _main(stack):
         dist.barrier()
         torch.cuda.synchronize(dev)
         tf = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(tf) for _ in range(world)]
+        dist.all_gather(per_rank, tf)
         dist.all_reduce(tf, op=dist.ReduceOp.MAX)
         gathered = saved
         filter_only = {"ms_per_step": float(tf.item()) / args.steps * 1e3,
                        "value": total * int(hb.Nmax) * args.steps / float(tf.item()), "unit": "track-steps/s",
+                       "per_rank_ms_per_step": [float(t.item()) / args.steps * 1e3 for t in per_rank],
                        "note": "the timed loop again, same pipeline (same CUs reserved), without the all-gather: what the "
                                "exchange costs is value against this"}
 
@@ -622,7 +690,7 @@ def _main(stack):
                              + "; zero injected noise; inputs resident in HBM"),
                 "total_tracks": total, "tracks_per_gpu": bmax, "steps_per_track": steps_per_track, "observations": NOBS,
                 "substeps": SUBSTEPS,
-                "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat overlapped with the next step" if gathered is not None else ""),
+                "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat {'of every step' if args.gather_every == 1 else f'once per {args.gather_every} steps'}, overlapped with the following steps" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
                              f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
                              + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing {pipe.forward_cus - pipe.reserve_cus} of the {pipe.forward_cus} CUs "
@@ -632,6 +700,7 @@ def _main(stack):
                                 f"on {pipe.forward_cus} CUs beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, ")
                              + f"{len(dbs)} sets of histories in rotation)"),
                 "lanes_per_track": args.lanes, "tuning": args.tuning, "untimed_prepass_steps": prepass,
+                "gather_every": args.gather_every if gathered is not None else None,
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms,
                            "timed_launches": len([e for e in evs if e is not None]),
@@ -736,6 +805,25 @@ def _main(stack):
                 "gpu_vs_oracle_max_rel_err_smoothed_means": parity["means_smoothed"]["max_rel_err"],
                 "gpu_vs_oracle": {"tracks": n, "tolerance": {"means_rel": 1e-6, "covs_rel_per_matrix": 1e-5}, **parity},
             }
+            if args.cpu_ref_tracks > 0:
+                nr = min(args.cpu_ref_tracks, n)
+                vr, sr, per_track = cpu_reference_call_sequence(nr)
+                got = db.download(("means", "covs", "means_smoothed", "covs_smoothed"), torch.arange(nr, device=dev))
+                pr = compare_histories(got, {k: np.stack([t[i] for t in per_track]) for i, k in
+                                             enumerate(("means", "covs", "means_smoothed", "covs_smoothed"))})
+                del got
+                out["cpu_baseline"]["reference_call_sequence"] = {
+                    "value": vr, "unit": "track-steps/s", "cores": 1, "kind": "port",
+                    "sample": f"{nr} tracks x {chb.Nmax} steps of the same batch, one after the other ({sr:.1f} s): "
+                              "oracle/ukf_oracle.py forward_track + backward_track, the restatement that issues the reference's "
+                              "own calls in its order (scipy.linalg.sqrtm per fan, a Python loop over the sigma points, "
+                              "np.linalg.pinv per gain; kalman_filter.py:61-117, unscented.py:285-351) and reproduces the "
+                              "reference bit for bit on every golden case -- the cost model of the reference's per-ship loop "
+                              "(examples/example_ukf_rts_smoother_batch.py:19-90) on this box's cores",
+                    "gpu_vs_this": {"tracks": nr, "means_max_rel_err": pr["means"]["max_rel_err"],
+                                    "means_smoothed_max_rel_err": pr["means_smoothed"]["max_rel_err"],
+                                    "covs_max_rel_err_per_matrix": pr["covs"]["max_rel_err_per_matrix"],
+                                    "covs_smoothed_max_rel_err_per_matrix": pr["covs_smoothed"]["max_rel_err_per_matrix"]}}
             if pool_result is not None:
                 out["cpu_baseline"]["all_cores"] = {
                     "value": pool_result[1], "unit": "track-steps/s", "cores": pool_result[0],

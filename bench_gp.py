@@ -157,6 +157,25 @@ def measure(tracks=1000, nobs=2000, evals=3, cpu_evals=2, fit=False):
                                "sample": f"{args.cpu_evals} objective evaluations at n={n} (oracle/gp_oracle.py: SciPy "
                                          "LAPACK cholesky/cho_solve, the same calls scikit-learn makes), BLAS threads = all it is given",
                                "gpu_vs_oracle_rel_err_lml": float(abs(lml[args.cpu_evals - 1] - l) / abs(l))}
+        # scikit-learn itself -- the library the reference's GPRegression.fit hands its data to (gaussian_process.py:63-66) --
+        # on the same objective: GaussianProcessRegressor.log_marginal_likelihood(theta, eval_gradient=True), the function
+        # its L-BFGS-B calls ~50 times per restart
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import RBF, ConstantKernel, WhiteKernel
+
+        gpr = GaussianProcessRegressor(kernel=ConstantKernel(1.0) * RBF(1.0) + WhiteKernel(0.5), optimizer=None)
+        gpr.fit(xs[0].reshape(-1, 1), ys[0])
+        t0 = time.perf_counter()
+        for k in range(args.cpu_evals):
+            lk, gk = gpr.log_marginal_likelihood(theta[0], eval_gradient=True)
+        dts = (time.perf_counter() - t0) / args.cpu_evals
+        out["cpu_baseline"]["scikit_learn"] = {
+            "value": 1.0 / dts, "unit": "track-objectives/s", "cores": host_core_share(), "kind": "reference",
+            "sample": f"{args.cpu_evals} calls of scikit-learn {__import__('sklearn').__version__} GaussianProcessRegressor."
+                      f"log_marginal_likelihood(theta, eval_gradient=True) at n={n} on track 0 ({dts:.2f} s each), BLAS threads = "
+                      "all it is given",
+            "gpu_vs_sklearn_rel_err_lml": float(abs(lml[0] - lk) / abs(lk)),
+            "gpu_vs_sklearn_rel_err_grad": float(np.max(np.abs(grad[0] - gk) / np.maximum(np.abs(gk), 1e-12)))}
     if args.fit:
         from track_estimators.gaussian_processes import gaussian_process as gpm
 

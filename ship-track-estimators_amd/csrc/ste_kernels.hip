@@ -10,6 +10,10 @@
 //                                        flag); with rts_work they also leave the smoother's cross-covariance D and,
 //                                        where it does not follow from the history, its x_b and P_b
 //   urtss_recur_l1                       smoother from those rows, one lane per track: gain K = D pinv(P_b), recurrence
+//                                        (batches that fill the chip)
+//   urtss_gains_all + urtss_recur_lean   the same smoother in two kernels for batches of <= 4 096 tracks: every gain of
+//     / urtss_recur_lean_q4              every (step, track) at once, written back into the work rows, then the bare
+//                                        recurrence, one lane or one DPP quad per track -- bit-identical to urtss_recur_l1
 //   urtss_backward_l1                    stand-alone smoother that recomputes everything (rts_work == NULL)
 //   predict / update / robust_terms / geodetic / sigma_points kernels   single-step API parity
 // All per-step inputs/outputs are SoA with the track index fastest, so a wave's accesses are contiguous runs.

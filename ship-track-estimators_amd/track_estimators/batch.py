@@ -644,10 +644,10 @@ class SmootherPipeline:
             # leave (its waves mostly wait for memory).
             forward_cus = ncu
         if forward_cus is None:
-            # The smoother moves ~450 B per track-step at ~28 GB/s per CU whatever the partition size (~90 CU-ms per
-            # 10 000 x 500 batch) and needs its workgroups (two per CU) in one round.  A lane-per-track forward pass costs
-            # ~160 CU-ms, a quad-per-track one ~280: five eighths of the chip for the former (160 + 96 CUs: 1.17 ms per
-            # step at 10 000 tracks; 144 + 112: 1.34, 168 + 88: 1.45), three quarters for the latter (192 + 64: 1.49).
+            # shared=False, the round 1-2 split (kept for measurements): the fraction of the chip the forward passes get was
+            # sized then, against a workgroup smoother that no longer exists -- five eighths for lane-per-track passes
+            # (160 + 96 CUs), three quarters for quad-per-track ones (192 + 64).  With today's kernels the same split
+            # measured 0.86 ms per step at 10 000 tracks against 0.68 shared; it is not re-tuned.
             forward_cus = (ncu * (3 if quad else 5) // (4 if quad else 8)) // 8 * 8
             # small devices / partitioned compute modes: keep at least one CU on either side of the split
             forward_cus = max(1, min(forward_cus if forward_cus > 0 else ncu // 2, ncu - 1))

@@ -377,6 +377,24 @@ def modern_robust_cases():
     return out
 
 
+_DEDUP_FULL = None  # set by modern_dedup_full_cases: the same runs, every row kept
+
+
+def modern_dedup_full_cases():
+    """modern_dedup_cases' reference runs with EVERY history row kept (the sampled fixture compares 1 545 of
+    ~75 000 rows): tests/golden/modern_ships_dedup_full.npz.  Also rewrites the sampled fixture from the same runs."""
+    global _DEDUP_FULL
+    _DEDUP_FULL = {}
+    try:
+        sampled = modern_dedup_cases()
+        full = dict(_DEDUP_FULL)
+    finally:
+        _DEDUP_FULL = None
+    full["ids"] = sampled["ids"]
+    np.savez_compressed(os.path.join(HERE, "modern_ships_dedup.npz"), **sampled)
+    return full
+
+
 def modern_dedup_cases():
     """BASELINE configs[3] beyond the two ships the reference can filter as they are: the five ids with duplicate
     timestamps, each read by the REFERENCE's ShipTrack from a file in which the rows that repeat the timestamp of the row
@@ -455,6 +473,19 @@ def modern_dedup_cases():
             out[f"{sid}_sens_{k}"] = (np.max(np.abs(a - b), axis=(-1, -2)) / np.max(np.abs(a), axis=(-1, -2)))[rows]
         out[f"{sid}_ok"] = np.int64(1 if finite else 0)
         out[f"{sid}_rows"] = rows
+        if _DEDUP_FULL is not None:
+            # EVERY row (modern_ships_dedup_full.npz): means in fp64; covariances as fp32 upper triangles -- 6e-8 of an entry,
+            # against a tolerance of 1e-5 of the matrix's largest entry -- and the sensitivities as fp32: 11 MB instead of 29
+            iu = np.triu_indices(4)
+            _DEDUP_FULL[f"{sid}_means"], _DEDUP_FULL[f"{sid}_means_smoothed"] = means, sm
+            _DEDUP_FULL[f"{sid}_covs_tri_f32"] = covs[:, iu[0], iu[1]].astype(np.float32)
+            _DEDUP_FULL[f"{sid}_covs_smoothed_tri_f32"] = sc[:, iu[0], iu[1]].astype(np.float32)
+            for k, a, b in (("means", means, means2), ("means_smoothed", sm, sm2)):
+                d = np.abs(a - b)
+                d[:, 3] = np.abs((a[:, 3] - b[:, 3] + 180.0) % 360.0 - 180.0)
+                _DEDUP_FULL[f"{sid}_sens_{k}"] = np.max(d / np.maximum(np.abs(a), 1e-3), axis=1).astype(np.float32)
+            for k, a, b in (("covs", covs, covs2), ("covs_smoothed", sc, sc2)):
+                _DEDUP_FULL[f"{sid}_sens_{k}"] = (np.max(np.abs(a - b), axis=(-1, -2)) / np.max(np.abs(a), axis=(-1, -2))).astype(np.float32)
         for k, v in (("means", means), ("covs", covs), ("means_smoothed", sm), ("covs_smoothed", sc)):
             out[f"{sid}_{k}"] = v[rows]
         print(f"modern dedup {sid}: T={len(st.lon)} N={N} finite={finite} sensitive sampled rows (> 1e-8): "
@@ -827,7 +858,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "two_runs.npz"), **two_runs_case())
     np.savez_compressed(os.path.join(HERE, "robust.npz"), **robust_cases())
     np.savez_compressed(os.path.join(HERE, "modern_ships_robust.npz"), **modern_robust_cases())
-    np.savez_compressed(os.path.join(HERE, "modern_ships_dedup.npz"), **modern_dedup_cases())
+    np.savez_compressed(os.path.join(HERE, "modern_ships_dedup_full.npz"), **modern_dedup_full_cases())  # + the sampled file
     np.savez_compressed(os.path.join(HERE, "track_prep.npz"), **prep_cases())
     np.savez_compressed(os.path.join(HERE, "batch_examples.npz"), **example_cases())
     np.savez_compressed(os.path.join(HERE, "cli_smooth.npz"), **smooth_case())
@@ -838,7 +869,7 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
-SELECTABLE = {"modern_dedup": (modern_dedup_cases, "modern_ships_dedup.npz"), "robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
+SELECTABLE = {"modern_dedup": (modern_dedup_cases, "modern_ships_dedup.npz"), "modern_dedup_full": (modern_dedup_full_cases, "modern_ships_dedup_full.npz"), "robust": (robust_cases, "robust.npz"), "modern_robust": (modern_robust_cases, "modern_ships_robust.npz"),
               "prep": (prep_cases, "track_prep.npz"), "examples": (example_cases, "batch_examples.npz"),
               "smooth": (smooth_case, "cli_smooth.npz"), "savgol": (savgol_case, "savgol_example.npz"),
               "illcond": (lambda: pack_cases(illcond_cases()), "ukf_illcond.npz")}

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """profiles/rNN_counters_per_track_step.csv and rNN_pmc_counters_per_launch.csv from the rocprofv3 --pmc passes of
-profiles/tools/pmc_passes_rNN.sh (usage: tools/write_profiles.py gpurun_out/<pmc dir> [round, default 04])."""
+profiles/tools/pmc_passes_rNN.sh (usage: tools/write_profiles.py gpurun_out/<pmc dir> [round, default 05]).
+
+The --stats pass and the --pmc passes must be of the same build: the script refuses to write anything when the filter kernels
+named in the kernel-stats file differ from the ones in the counter files (round 4 committed a stats file taken before the
+forward kernel gained a template parameter)."""
 import collections
 import csv
 import glob
@@ -9,7 +13,7 @@ import shutil
 import sys
 
 root = sys.argv[1]
-RN = "r" + (sys.argv[2] if len(sys.argv) > 2 else "04")
+RN = "r" + (sys.argv[2] if len(sys.argv) > 2 else "05")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -26,6 +30,15 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
 names = sorted({n for k in acc for n in acc[k]})
 if not acc or not all(k in acc for _, k in [("f", "ste::ukf_forward_l1<true, true, false>")]):
     sys.exit(f"no counter files of the filter kernels under {root}: nothing written")
+# the --stats pass must name the same filter kernels as the counter passes (same build)
+stats_files = glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats_files:
+    norm = lambda n: n.replace("void ", "").replace("(ste::KParams)", "")  # noqa: E731
+    in_stats = {norm(r["Name"]) for r in csv.DictReader(open(stats_files[0])) if norm(r["Name"]).startswith("ste::")}
+    filt = lambda names_: {n for n in names_ if n.startswith(("ste::ukf_forward", "ste::urtss_"))}  # noqa: E731
+    if filt(in_stats) != filt(acc):
+        sys.exit("kernel-stats pass and counter passes are of different builds:\n  stats only:    %s\n  counters only: %s\nnothing written"
+                 % (sorted(filt(in_stats) - filt(acc)), sorted(filt(acc) - filt(in_stats))))
 TS = 5.0e6
 with open(f"profiles/{RN}_pmc_counters_per_launch.csv", "w") as f:
     f.write("# rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 2 --cpu-tracks 0 --no-gp\n")
@@ -54,9 +67,9 @@ with open(f"profiles/{RN}_counters_per_track_step.csv", "w") as f:
         f.write('%s,"%s",%.2f,%.2f,%.1f,%.1f,%.1f,%.1f,%d,%.3f\n' % (
             short, k, c["FETCH_SIZE"] * 2048 / TS, c["WRITE_SIZE"] * 1024 / TS, flops, c["SQ_INSTS_VALU"] / w / 500,
             c["SQ_INSTS_SALU"] / w / 500, sum(f64) / w / 500, w, sum(dur[k]) / len(dur[k])))
-for src, dst in (("stats/runc/*kernel_stats.csv", f"profiles/{RN}_pipelined_kernel_stats.csv"), ("bench_k100.json", f"profiles/{RN}_bench_default.json"),
+for src, dst in (("stats/**/*kernel_stats.csv", f"profiles/{RN}_pipelined_kernel_stats.csv"), ("bench_k100.json", f"profiles/{RN}_bench_default.json"),
                  ("bench_driver_form.json", f"profiles/{RN}_bench_driver_form.json")):
-    m = glob.glob(os.path.join(root, src))
+    m = glob.glob(os.path.join(root, src), recursive=True)
     if m:
         shutil.copy(m[0], dst)
 print(open(f"profiles/{RN}_counters_per_track_step.csv").read())
