@@ -389,6 +389,12 @@ def _main(stack):
                     help="keep the covariance histories as full 4x4 matrices in HBM (default: packed upper triangles)")
     ap.add_argument("--slices", type=int, default=None,
                     help="time slices per pipelined forward pass (default: batch.DEFAULT_SLICES)")
+    ap.add_argument("--sequence", default="auto",
+                    help="steps per SCHEDULED forward launch (SmootherPipeline.submit_sequence: the forward passes of that many "
+                         "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
+                         "step, or 'auto' = 10 when --steps <= 40 (a short run is all fill and drain, which the schedule "
+                         "shortens: 0.77 against 0.80 ms per step at the driver's 20 steps), 0 for longer runs (in the steady "
+                         "state per-step launches re-balance by themselves and are 2-4 %% faster; DESIGN.md section 5)")
     ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
     ap.add_argument("--fleet-tracks", type=int, default=100_000)
     ap.add_argument("--fleet-chunk", type=int, default=None, help="window size of the fleet entry (default: batch.FLEET_CHUNK)")
@@ -481,7 +487,14 @@ def _main(stack):
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
         except (binding.SteError, ValueError) as exc:  # no CU-masked streams here, or a batch too large to partition
             print(f"[bench] pipelining disabled, steps run back to back: {exc}", file=sys.stderr, flush=True)
-    dbs = [db] if pipe is None else [db] + [mk() for _ in range(pipe.buffers_needed - 1)]
+    seq = 0
+    if pipe is not None and args.lanes != 4 and (args.forward_lanes in (None, 1)):
+        # auto: single-GPU runs only (with an exchange in the step the per-step launches are the measured configuration)
+        seq = (10 if (args.steps <= 40 and dist is None) else 0) if args.sequence == "auto" else int(args.sequence)
+    # per-step launches rotate through buffers_needed sets; a scheduled launch needs a set per step of the sequence, and two
+    # sequences' worth so that the next sequence does not wait for the smoothers of the one before it
+    nsets = 1 if pipe is None else max(pipe.buffers_needed, min(2 * seq, max(args.steps, args.warmup)))
+    dbs = [db] + [mk() for _ in range(nsets - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
         # the one exchange of the path: all-gather of the smoothed lon/lat, overlapped with the next step's kernels
@@ -517,6 +530,28 @@ def _main(stack):
             pipe.submit(d, after_smoother=(lambda _s: gathered.launch_for_pipeline(d.sm_pos)) if exchange else None,
                         timing=events, final=final)
 
+    seq_timings = []
+
+    def run_steps(nsteps, events=None):
+        """`nsteps` steps of the hot path: one launch pair per step, or -- `seq` > 0 -- the forward passes of every `seq`
+        consecutive steps as one scheduled launch (each step still filters and smooths its own batch into its own buffers)."""
+        if not seq:
+            for k in range(nsteps):
+                one_step(k, None if events is None else events[k], final=(k == nsteps - 1))
+            return
+        for c0 in range(0, nsteps, seq):
+            ks = list(range(c0, min(c0 + seq, nsteps)))
+            tm = {} if events is not None else None
+            hook = None
+            if gathered is not None:
+                def hook(i, _s, ks=ks):  # noqa: E306
+                    if (ks[i] + 1) % args.gather_every == 0:
+                        return gathered.launch_for_pipeline(dbs[ks[i] % len(dbs)].sm_pos)
+                    return None
+            pipe.submit_sequence([dbs[k % len(dbs)] for k in ks], after_smoother=hook, timing=tm, final=(ks[-1] == nsteps - 1))
+            if tm is not None:
+                seq_timings.append((len(ks), tm))
+
     def drain():
         if pipe is not None:
             pipe.synchronize()
@@ -543,11 +578,9 @@ def _main(stack):
     # Untimed pre-pass: every set of history buffers of the rotation goes through the path once, so that nothing the
     # timed region uses is touched for the first time inside it (the driver's run has fewer warm-up steps than sets).
     prepass = len(dbs) if pipe is not None else 0
-    for k in range(prepass):
-        one_step(k, final=(k == prepass - 1))
+    run_steps(prepass)
     drain()
-    for k in range(args.warmup):
-        one_step(k, final=(k == args.warmup - 1))
+    run_steps(args.warmup)
     drain()
     if dist is not None:
         dist.barrier()
@@ -558,8 +591,7 @@ def _main(stack):
     every = EVENT_EVERY
     evs = [[ev(), ev(), ev(), ev()] if k % every == 0 else None for k in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(k, evs[k], final=(k == args.steps - 1))  # the last smoother has nothing to hide behind: whole chip
+    run_steps(args.steps, evs)  # (the last smoother has nothing to hide behind: it gets the whole chip)
     drain()  # every step's smoother (and gathered result) has landed before the clock stops
     if dist is not None:
         dist.barrier()
@@ -615,8 +647,7 @@ def _main(stack):
         torch.cuda.synchronize(dev)
         dist.barrier()
         t1 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(k, None, final=(k == args.steps - 1))
+        run_steps(args.steps)
         drain()
         dist.barrier()
         torch.cuda.synchronize(dev)
@@ -631,12 +662,18 @@ def _main(stack):
                        "note": "the timed loop again, same pipeline (same CUs reserved), without the all-gather: what the "
                                "exchange costs is value against this"}
 
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs if e is not None]))
-    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs if e is not None]))
+    if seq_timings:  # scheduled launches: one forward kernel per sequence, a smoother per step
+        fwd_ms = float(np.mean([tm["forward"][0].elapsed_time(tm["forward"][1]) for _n, tm in seq_timings]))
+        bwd_ms = float(np.mean([a.elapsed_time(b) for _n, tm in seq_timings for a, b in tm["smoothers"]]))
+        steps_per_launch = float(np.mean([n for n, _tm in seq_timings]))
+    else:
+        fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs if e is not None]))
+        bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs if e is not None]))
+        steps_per_launch = 1.0
     # Steady state of the pipeline: completed steps between two completion events (end of a step's smoother), leaving out
     # the steps during which the pipeline fills (no smoother has anything to do yet) and drains (no forward pass left).
     steady = None
-    if pipe is not None:
+    if pipe is not None and not seq:
         skip = len(pipe.fwd_streams) + 1
         # completions come in bursts (forward passes run in generations of as many launches as fill the chip), so the
         # window has to span several of them: at the driver's K = 20 there is no such window and the object is null
@@ -661,7 +698,7 @@ def _main(stack):
         cf = counters.get("ukf_forward", {})
         cb = counters.get("urtss_backward", {})
         # dominant kernel: the forward filter (it holds its partition for the whole step; the smoother hides behind it)
-        achieved = BYTES_FWD * track_steps_rank / (fwd_ms * 1e-3) / 1e9
+        achieved = BYTES_FWD * track_steps_rank * steps_per_launch / (fwd_ms * 1e-3) / 1e9
         per_s = track_steps_rank * args.steps / elapsed  # this rank's rate over the timed region
         traffic_fwd = (cf["hbm_read"] + cf["hbm_write"]) * track_steps_rank if "hbm_read" in cf else None
         traffic_all = None
@@ -692,6 +729,10 @@ def _main(stack):
                 "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat {'of every step' if args.gather_every == 1 else f'once per {args.gather_every} steps'}, overlapped with the following steps" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
+                             (f"the forward passes of every {seq} steps as ONE scheduled launch of {4 * (pipe.forward_cus - pipe.reserve_cus)} resident "
+                              "waves over (64-track tile, 64-step slice) items (SmootherPipeline.submit_sequence; bit-identical to "
+                              f"per-step launches), each step's smoother behind a gate on one of {len(pipe.bwd_streams)} smoother streams, "
+                              f"{len(dbs)} sets of histories in rotation") if seq else
                              f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
                              + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing {pipe.forward_cus - pipe.reserve_cus} of the {pipe.forward_cus} CUs "
                                 + (f"({pipe.reserve_cus} left to the collective's kernels) " if pipe.reserve_cus else "") +
@@ -700,11 +741,15 @@ def _main(stack):
                                 f"on {pipe.forward_cus} CUs beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, ")
                              + f"{len(dbs)} sets of histories in rotation)"),
                 "lanes_per_track": args.lanes, "tuning": args.tuning, "untimed_prepass_steps": prepass,
+                "steps_per_scheduled_forward_launch": seq,
                 "gather_every": args.gather_every if gathered is not None else None,
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms,
-                           "timed_launches": len([e for e in evs if e is not None]),
-                           "note": f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region"},
+                           "timed_launches": len(seq_timings) if seq else len([e for e in evs if e is not None]),
+                           "steps_per_forward_launch": steps_per_launch,
+                           "note": ("HIP events around every scheduled forward launch (the forward passes of "
+                                    f"{steps_per_launch:g} steps each) and around every step's smoother" if seq else
+                                    f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region")},
             "steady_state": steady,
             "all_gather_alone": gather_alone,
             "filter_only": filter_only,
@@ -740,8 +785,9 @@ def _main(stack):
                     "time_slices_per_launch": 1 if pipe is None else pipe.slices,
                     "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "unit": "GB/s",
                     "traffic": traffic_fwd, "traffic_unit": "bytes per launch",
-                    "launches_in_flight": 1 if pipe is None else len(pipe.fwd_streams),
-                    "aggregate": None if pipe is None else {
+                    "steps_per_launch": steps_per_launch,
+                    "launches_in_flight": 1 if (pipe is None or seq) else len(pipe.fwd_streams),
+                    "aggregate": None if (pipe is None or seq) else {
                         "achieved": achieved * len(pipe.fwd_streams), "frac": achieved * len(pipe.fwd_streams) / HBM_PEAK_GBS,
                         "unit": "GB/s", "note": "algorithmic bytes of the forward launches in flight together over one launch duration"},
                     "alone": None if "alone_ms" not in cf else {

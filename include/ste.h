@@ -43,8 +43,10 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 310 /* 0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in time slices (step_begin /
-                           step_end).  0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma weights sum to one */
+#define STE_VERSION 320 /* 0.3.2: the forward passes of many windows as one scheduled launch (ste_ukf_forward_sched_f64,
+                           ste_stream_wait_counter).  0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in
+                           time slices (step_begin / step_end).  0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma
+                           weights sum to one */
 
 /* error codes */
 #define STE_OK 0
@@ -193,6 +195,49 @@ int ste_device_count(void);
 
 /* Forward UKF over all steps of every track: writes fwd_mean, fwd_cov, status. */
 int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream);
+
+/* ---- 0.3.2 -------------------------------------------------------------------------------------------------------
+ * The forward passes of MANY windows (or batches) as ONE launch.  The reference's batch dimension is its per-ship loop
+ * (examples/example_ukf_rts_smoother_batch.py:19-90); a fleet goes through the GPU as windows (track_stride above), and
+ * with one launch per window a forward wave -- 64 tracks for the whole pass -- is indivisible: W windows of T tiles on S
+ * SIMDs cost ceil(W T / S) pass times for W T / S pass times of work.  Here the unit is a (64-track tile, time slice) item,
+ * the launch is `nwaves` resident waves (one per SIMD the stream may use), and `items` says which item every wave runs in
+ * every round.  A tile's slices may run on different waves: each slice starts from the history row the one before it
+ * left (the slices of ste_ukf_forward_f64: same bits as a whole pass), publishes the tile's slice count when its rows are
+ * in memory, and the next slice waits for that count -- always an item of an EARLIER round.  The library checks the table
+ * (every tile of every window runs all its slices, in order, at most one per round) before anything is launched, and
+ * every in-kernel wait is bounded: a launch that cannot progress sets *error and ends.
+ *
+ * window_done[w] counts the finished tiles of window w: ste_stream_wait_counter(window_done + w, tiles of w, ...) on another
+ * stream holds that stream until the window's forward pass is complete (its smoother goes behind it).
+ *
+ * All windows must take the same kernel (same H / R structure, robust flag, rts_work present or not); lane-per-track
+ * mapping only.  host_ws must be page-locked for the upload to be asynchronous and stay untouched until the launch has
+ * started; dev_ws is filled by the call's own stream operations.  window_done and error must be ZERO when the launch starts:
+ * the caller clears them on `stream` before the call (and orders every stream that will wait on a counter behind that
+ * clearing), the call does not. */
+typedef struct ste_fwd_sched_f64 {
+    int32_t nwindows;
+    const ste_ukf_batch_f64* windows; /* HOST [nwindows]; step_begin = step_end = 0 */
+    int32_t slice_steps;              /* steps per time slice, a multiple of STE_SLICE_ALIGN; 0 = STE_SLICE_ALIGN */
+    int32_t nwaves;                   /* waves of the launch; all must be resident at once: <= SIMDs the stream may use */
+    int32_t nrounds;
+    const int32_t* items;             /* HOST [nrounds][nwaves][2]: (window, tile of that window), window < 0 = idle */
+    void* host_ws;                    /* HOST scratch, ws_bytes (ste_ukf_forward_sched_workspace) */
+    void* dev_ws;                     /* DEVICE scratch, ws_bytes */
+    size_t ws_bytes;
+    int32_t* window_done;             /* DEVICE [nwindows], zero at launch */
+    int32_t* error;                   /* DEVICE [1], zero at launch: 1 = a forward wait timed out, 2 = a gate (wait_counter) did */
+    double timeout_s;                 /* bound of one in-kernel wait; 0 = 2 s */
+} ste_fwd_sched_f64;
+
+/* bytes of host_ws / dev_ws for a schedule of that shape (max_slices = largest ceil(Nmax / slice_steps) over the windows) */
+size_t ste_ukf_forward_sched_workspace(int32_t nwindows, int32_t max_slices, int64_t ntiles_total, int32_t nrounds,
+                                       int32_t nwaves);
+int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream);
+
+/* Holds `stream` (a one-wave kernel) until *counter >= need; after timeout_s (0 = 2 s) it gives up and sets *error = 2. */
+int ste_stream_wait_counter(const int32_t* counter, int32_t need, int32_t* error, double timeout_s, void* stream);
 
 /* Unscented RTS smoother: reads fwd_mean/fwd_cov, writes sm_mean/sm_cov, ORs status. */
 int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream);

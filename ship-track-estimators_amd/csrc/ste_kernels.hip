@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ste.h"
 #include "ste_err.h"
@@ -81,6 +82,11 @@ __device__ __forceinline__ int late_k0() {
     kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     return *(const volatile int __attribute__((address_space(4)))*)(ka + offsetof(KParams, k0));
 }
+
+// The scheduled forward kernel (ukf_forward_sched) has no KParams in its argument segment: the work item's slice offset is
+// parked in a word of LDS (one wave per workgroup) and read back where it is used, for the same reason.
+__shared__ int g_sched_word[2];  // [0] the slice offset k0 of the item being run, [1] the wave's position in its item list
+__device__ __forceinline__ int sched_k0() { return *(volatile int*)&g_sched_word[0]; }
 
 constexpr int kColdEvery = 64;  // power of two
 
@@ -578,7 +584,7 @@ __device__ __forceinline__ int ukf_update(const Mats& p, double (&x)[4], double 
 // also leaves the smoother's row of this step (see kWorkD).  x, P are replaced by the predicted mean (+ recorded noise)
 // and covariance.  `flagged` is sticky: set once a square root of this track was clamped or did not converge; from that
 // step on columns 2-3 of D are stored as well.
-template <bool kGains>
+template <bool kGains, bool kSched = false>
 __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], double (&P)[10], double (&V)[4][4], bool warm,
                                             double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, size_t nrow, size_t B, size_t t, double* work,
@@ -672,7 +678,7 @@ __device__ __forceinline__ int lane_predict(const Mats& p, double (&x)[4], doubl
             st_stream(&w[(kWorkD + 7) * B], Pn[tix(1, 3)]);
         }
         const bool bad_now = (st & (STE_STATUS_CLAMPED | STE_STATUS_NOCONV)) != 0;
-        if (bad_now && !flagged) *first_bad = (double)((long long)nrow + late_k0());  // absolute step index
+        if (bad_now && !flagged) *first_bad = (double)((long long)nrow + (kSched ? sched_k0() : late_k0()));  // absolute step index
         flagged = flagged || bad_now;
         if (flagged) {  // columns 2-3 of D = 2 wi (T T)[:, 2:4]: (2 wi scale) P_k[:, 2:4] only for an exact square root
             st_stream(&w[(kWorkD23 + 0) * B], two_wi * f.TT[0][0]);
@@ -777,10 +783,9 @@ __device__ __forceinline__ void store_hist(const KParams& p, size_t row, size_t 
 // kRobust: the closed-form update with the closed-form robust rescaling in front of it (a template parameter, so that the
 // default instantiation's step loop is exactly the one measured without it); with kFastUpd false the general route reads
 // robust_iters itself.
-template <bool kGains, bool kFastUpd, bool kRobust = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
+template <bool kGains, bool kFastUpd, bool kRobust, bool kSched>
+__device__ __forceinline__ void forward_tile_l1(const KParams& p, const size_t t) {
     const size_t B = (size_t)p.ld;  // row pitch of every per-track array (= the batch's own width unless it is a window)
-    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= (size_t)p.B) return;
     // A later time slice of a forward pass (slice_params): x0 / P0 name history row k0 -- the state the previous launch
     // left, bit for bit -- and every per-step pointer row k0; the slice boundary is a multiple of kColdEvery, where the
@@ -843,8 +848,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int c = 0; c < 4; ++c) xc[c] = x[c];
         STE_UNROLL
         for (int e = 0; e < 10; ++e) Pc[e] = P[e];
-        st |= lane_predict<true>(p.m, xc, Pc, V, false, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts, 0, B, t,
-                                 p.rts_work, true, noise_mode, flagged, first_bad, tk, Qv);
+        st |= lane_predict<true, kSched>(p.m, xc, Pc, V, false, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts, 0, B, t,
+                                         p.rts_work, true, noise_mode, flagged, first_bad, tk, Qv);
     }
     if (initial_update) {
         double z0[4];
@@ -885,8 +890,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // row 0's smoother rows were taken from the prior above; every later row k is the state this predict starts from
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             const bool warm = (k & (kColdEvery - 1)) != 0;
-            st |= lane_predict<kGains>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
-                                       upd || noise_mode, noise_mode, flagged, first_bad, tk, Qv);
+            st |= lane_predict<kGains, kSched>(p.m, x, P, V, warm, dt, sr, cr, p.noise_pred, p.noise_rts, (size_t)k, B, t, work,
+                                               upd || noise_mode, noise_mode, flagged, first_bad, tk, Qv);
             if (upd) st |= lane_update<kFastUpd, kRobust>(p.m, x, P, zk, p.noise_upd, (size_t)k + 1, B, t);
             if (!ui_ok) st |= STE_STATUS_BAD_INDEX;
             store_hist(p, (size_t)k + 1, B, t, x, P);
@@ -899,6 +904,96 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int e = 0; e < 10; ++e) chk += P[e] * 0.0;
     if (!(chk == 0.0)) st |= STE_STATUS_NAN;  // inf*0 and nan*0 are NaN
     p.status[t] = st;
+}
+
+template <bool kGains, bool kFastUpd, bool kRobust = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_l1(const KParams p) {
+    forward_tile_l1<kGains, kFastUpd, kRobust, false>(p, (size_t)blockIdx.x * 64 + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The forward passes of MANY windows as one launch of resident waves working through a host-made schedule
+// (ste_ukf_forward_sched_f64; DESIGN.md section 5, "Scheduled forward pass").
+//
+// A forward wave is indivisible for a whole pass (3.6-4.5 ms at 500 steps) when every window is a launch of its own: W
+// windows of T tiles on S SIMDs then cost ceil(W T / S) pass times although they hold only W T / S pass times of work --
+// the driver's 20 steps (3 140 tiles on 1 024 SIMDs) pay 4 generations for 3.07, a 100 000-track fleet 2 for 1.53.  Here the
+// unit of work is a (tile, time slice) ITEM -- 64 tracks x one STE_SLICE_ALIGN-aligned step range, the slices of
+// ste_ukf_forward_f64, bit-identical because a slice starts from the history row the previous one left -- and the launch
+// is one wave per SIMD, each walking its own column of a [rounds][waves] item table.  Slices of one tile may run on
+// different waves: a finished slice publishes the tile's slice count (release, agent scope: its history rows, work rows and
+// status are in memory before the count moves) and the next slice acquires it.  The table comes from the host, which checks
+// that every tile's slices appear in order, at most one per round -- so a wait only ever looks at an EARLIER round, and with
+// all waves resident (the launch is sized to the SIMDs its stream may use) it is satisfied without spinning in the common
+// case.  Every wait is bounded (s_memrealtime): a schedule that cannot progress raises the launch's error word and every
+// wave leaves, instead of hanging the device.
+// A window whose tiles have all finished their last slice bumps window_done[w]; smoothers wait for that count
+// (ste_stream_wait_counter: a one-wave gate kernel on the smoother's stream).
+// ---------------------------------------------------------------------------------------------------------------
+struct SchedItem {
+    int kp;    // index into the KParams table (one entry per (window, slice)), < 0: nothing to do this round
+    int tile;  // 64-track tile of that window
+    int prog;  // index of the tile's progress counter
+    int meta;  // slice | last-slice flag << 8 | window << 9
+};
+struct SchedParams {
+    const KParams* kps;
+    const SchedItem* items;  // [nrounds][nwaves]
+    int nrounds, nwaves;
+    int* progress;     // [tiles of all windows] slices finished, zeroed before the launch
+    int* window_done;  // [nwindows] tiles finished, zeroed before the launch
+    int* error;        // one word, zeroed before the launch: 1 = a wait timed out (the schedule could not progress)
+    unsigned long long timeout_ticks;  // bound of a single wait, in s_memrealtime ticks (100 MHz)
+};
+
+// wave-uniform: spin (sleeping) until *flag >= need or the bound is reached
+__device__ __forceinline__ bool sched_wait(const int* flag, int need, unsigned long long timeout_ticks) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) return false;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+template <bool kGains, bool kFastUpd, bool kRobust>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_sched(const SchedParams sp) {
+    typedef const KParams __attribute__((address_space(4))) ConstKParams;  // the table is constant for the launch: scalar loads,
+                                                                           // re-materialised where they are used like kernel arguments
+    for (int r = 0; r < sp.nrounds; ++r) {
+        const SchedItem* ip = sp.items + ((size_t)r * sp.nwaves + blockIdx.x);
+        const int kp = __builtin_amdgcn_readfirstlane(ip->kp);
+        if (kp < 0) continue;
+        const int tile = __builtin_amdgcn_readfirstlane(ip->tile), prog = __builtin_amdgcn_readfirstlane(ip->prog);
+        const int meta = __builtin_amdgcn_readfirstlane(ip->meta);
+        const int slice = meta & 0xff;
+        if (__hip_atomic_load(sp.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (slice > 0 && !sched_wait(sp.progress + prog, slice, sp.timeout_ticks)) {
+            if (threadIdx.x == 0) __hip_atomic_store(sp.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const KParams& p = *(const KParams*)(ConstKParams*)(uintptr_t)(sp.kps + kp);
+        if (threadIdx.x == 0) *(volatile int*)&g_sched_word[0] = p.k0;
+        forward_tile_l1<kGains, kFastUpd, kRobust, true>(p, (size_t)tile * 64 + threadIdx.x);
+        // publish: this wave's stores have been acknowledged, then made visible at agent scope, before the count moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(sp.progress + prog, slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (meta & 0x100) __hip_atomic_fetch_add(sp.window_done + (meta >> 9), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// One wave that leaves when *counter >= need (or after the bound, raising *error): what a smoother's stream runs in front of
+// the smoother of a window whose forward pass is part of a scheduled launch on another stream.
+__global__ __launch_bounds__(64) void sched_gate(const int* counter, int need, int* error, unsigned long long timeout_ticks) {
+    if (!sched_wait(counter, need, timeout_ticks) && threadIdx.x == 0 && error)
+        __hip_atomic_store(error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 
@@ -2381,6 +2476,26 @@ int launch_backward(const ste::KParams& kp, hipStream_t s) {
     return check_hip(hipGetLastError(), "urtss_backward launch");
 }
 
+// which instantiation of the lane-per-track forward kernel a batch takes (launch_forward's own choice, as a number)
+int forward_variant(const ste::KParams& kp) {
+    const bool robust = kp.m.robust_iters > 0;
+    return (kp.fast_upd ? (robust ? 4 : 2) : 0) | (kp.rts_work ? 1 : 0);
+}
+
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+struct SchedLayout {
+    size_t kps, items, progress, total;  // byte offsets into the workspace (kps and items are uploaded, progress is zeroed)
+};
+SchedLayout sched_layout(size_t nkp, size_t nitems, size_t ntiles) {
+    SchedLayout l;
+    l.kps = 0;
+    l.items = align16(nkp * sizeof(ste::KParams));
+    l.progress = l.items + align16(nitems * sizeof(ste::SchedItem));
+    l.total = l.progress + align16(ntiles * sizeof(int));
+    return l;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2439,6 +2554,130 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream) {
     rc = slice_params(b, &kp);
     if (rc) return rc;
     return launch_forward(kp, (hipStream_t)stream);
+}
+
+size_t ste_ukf_forward_sched_workspace(int32_t nwindows, int32_t max_slices, int64_t ntiles_total, int32_t nrounds,
+                                       int32_t nwaves) {
+    if (nwindows < 0 || max_slices < 0 || ntiles_total < 0 || nrounds < 0 || nwaves < 0) return 0;
+    return sched_layout((size_t)nwindows * (size_t)max_slices, (size_t)nrounds * (size_t)nwaves, (size_t)ntiles_total).total;
+}
+
+int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
+    if (!sc) return fail(STE_EINVAL, "schedule pointer is NULL");
+    if (sc->nwindows < 1 || !sc->windows) return fail(STE_EINVAL, "scheduled forward pass: nwindows >= 1 and windows are required");
+    if (sc->nwaves < 1 || sc->nrounds < 1 || !sc->items) return fail(STE_EINVAL, "scheduled forward pass: nwaves, nrounds >= 1 and items are required");
+    if (!sc->host_ws || !sc->dev_ws || !sc->window_done || !sc->error)
+        return fail(STE_EINVAL, "scheduled forward pass: host_ws, dev_ws, window_done and error are required");
+    const int step = sc->slice_steps ? sc->slice_steps : STE_SLICE_ALIGN;
+    if (step < STE_SLICE_ALIGN || step % STE_SLICE_ALIGN != 0)
+        return fail(STE_EINVAL, "scheduled forward pass: slice_steps must be a positive multiple of STE_SLICE_ALIGN (64)");
+    if (sc->nwindows >= (1 << 22)) return fail(STE_EINVAL, "scheduled forward pass: too many windows");
+    // per window: slices, tiles, and where its KParams and progress counters start
+    std::vector<int> nslices((size_t)sc->nwindows), kp0((size_t)sc->nwindows), tile0((size_t)sc->nwindows + 1);
+    size_t nkp = 0, ntiles = 0;
+    int max_slices = 0;
+    for (int w = 0; w < sc->nwindows; ++w) {
+        const ste_ukf_batch_f64& b = sc->windows[w];
+        if (b.B <= 0 || b.Nmax < 0) return fail(STE_EINVAL, "scheduled forward pass: a window has B <= 0 or Nmax < 0");
+        if (b.step_begin != 0 || b.step_end != 0) return fail(STE_EINVAL, "scheduled forward pass: windows must not carry a step range of their own");
+        if (b.flags & STE_FLAG_LANES_4) return fail(STE_EINVAL, "scheduled forward pass: lane-per-track only (STE_FLAG_LANES_4 is set)");
+        nslices[w] = std::max(1, (b.Nmax + step - 1) / step);
+        if (nslices[w] > 255) return fail(STE_EINVAL, "scheduled forward pass: more than 255 time slices per window; raise slice_steps");
+        max_slices = std::max(max_slices, nslices[w]);
+        kp0[w] = (int)nkp;
+        tile0[w] = (int)ntiles;
+        nkp += (size_t)nslices[w];
+        ntiles += ((size_t)b.B + 63) / 64;
+        if (ntiles > 0x7fffffff) return fail(STE_EINVAL, "scheduled forward pass: too many tiles");
+    }
+    tile0[sc->nwindows] = (int)ntiles;
+    const size_t nitems = (size_t)sc->nrounds * (size_t)sc->nwaves;
+    const SchedLayout lay = sched_layout(nkp, nitems, ntiles);
+    if (sc->ws_bytes < lay.total) return fail(STE_EINVAL, "scheduled forward pass: workspace too small (ste_ukf_forward_sched_workspace)");
+    char* hw = (char*)sc->host_ws;
+    ste::KParams* kps = (ste::KParams*)(hw + lay.kps);
+    int variant = -1;
+    for (int w = 0; w < sc->nwindows; ++w) {
+        for (int q = 0; q < nslices[w]; ++q) {
+            ste_ukf_batch_f64 b = sc->windows[w];
+            b.flags |= STE_FLAG_LANES_1;
+            b.step_begin = q * step;
+            b.step_end = std::min(b.Nmax, (q + 1) * step);
+            ste::KParams* kp = kps + kp0[w] + q;
+            int rc = make_params(&b, false, false, kp);
+            if (rc) return rc;
+            rc = slice_params(&b, kp);
+            if (rc) return rc;
+            const int v = forward_variant(*kp);
+            if (variant >= 0 && v != variant)
+                return fail(STE_EINVAL, "scheduled forward pass: the windows must agree on H / R structure, robust flag and rts_work (one kernel runs them all)");
+            variant = v;
+        }
+    }
+    // items: (window, tile) per (round, wave); the slice is the tile's number of earlier appearances.  Every tile must run
+    // all its slices, in rounds that strictly increase.
+    ste::SchedItem* items = (ste::SchedItem*)(hw + lay.items);
+    std::vector<int> next_slice(ntiles, 0), last_round(ntiles, -1);
+    for (int r = 0; r < sc->nrounds; ++r)
+        for (int v = 0; v < sc->nwaves; ++v) {
+            const size_t i = (size_t)r * sc->nwaves + v;
+            const int w = sc->items[2 * i], tile = sc->items[2 * i + 1];
+            ste::SchedItem it = {-1, 0, 0, 0};
+            if (w >= 0) {
+                if (w >= sc->nwindows) return fail(STE_EINVAL, "scheduled forward pass: an item names a window that does not exist");
+                if (tile < 0 || tile >= tile0[w + 1] - tile0[w]) return fail(STE_EINVAL, "scheduled forward pass: an item names a tile outside its window");
+                const int g = tile0[w] + tile, q = next_slice[g];
+                if (q >= nslices[w]) return fail(STE_EINVAL, "scheduled forward pass: a tile is scheduled for more slices than it has");
+                if (last_round[g] >= r) return fail(STE_EINVAL, "scheduled forward pass: two slices of one tile in the same round");
+                next_slice[g] = q + 1;
+                last_round[g] = r;
+                it.kp = kp0[w] + q;
+                it.tile = tile;
+                it.prog = g;
+                it.meta = q | (q + 1 == nslices[w] ? 0x100 : 0) | (w << 9);
+            }
+            items[i] = it;
+        }
+    for (int w = 0; w < sc->nwindows; ++w)
+        for (int g = tile0[w]; g < tile0[w + 1]; ++g)
+            if (next_slice[g] != nslices[w]) return fail(STE_EINVAL, "scheduled forward pass: a tile is missing slices (every tile of every window must run all of them)");
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return fail(STE_ENOGPU, "no HIP device");
+    // every wave of the launch must be resident at once (a wait may look at any other wave's earlier rounds): one per SIMD
+    if (sc->nwaves > 4 * ncu) return fail(STE_EINVAL, "scheduled forward pass: nwaves exceeds the device's SIMD count (4 per compute unit)");
+    hipStream_t s = (hipStream_t)stream;
+    char* dw = (char*)sc->dev_ws;
+    int rc = check_hip(hipMemcpyAsync(dw, hw, lay.progress, hipMemcpyHostToDevice, s), "scheduled forward pass: table upload");
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(dw + lay.progress, 0, lay.total - lay.progress, s), "scheduled forward pass: counters");
+    if (rc) return rc;
+    ste::SchedParams sp;
+    sp.kps = (const ste::KParams*)(dw + lay.kps);
+    sp.items = (const ste::SchedItem*)(dw + lay.items);
+    sp.nrounds = sc->nrounds;
+    sp.nwaves = sc->nwaves;
+    sp.progress = (int*)(dw + lay.progress);
+    sp.window_done = sc->window_done;
+    sp.error = sc->error;
+    sp.timeout_ticks = (unsigned long long)((sc->timeout_s > 0 ? sc->timeout_s : 2.0) * 1e8);
+    const dim3 grid((unsigned)sc->nwaves), block(64);
+    switch (variant) {
+#define STE_SCHED(n, g, f, r) \
+    case n: hipLaunchKernelGGL((ste::ukf_forward_sched<g, f, r>), grid, block, 0, s, sp); break;
+        STE_SCHED(0, false, false, false) STE_SCHED(1, true, false, false) STE_SCHED(2, false, true, false)
+        STE_SCHED(3, true, true, false) STE_SCHED(4, false, true, true) STE_SCHED(5, true, true, true)
+#undef STE_SCHED
+        default: return fail(STE_EINVAL, "scheduled forward pass: no kernel variant");
+    }
+    return check_hip(hipGetLastError(), "ukf_forward_sched launch");
+}
+
+int ste_stream_wait_counter(const int32_t* counter, int32_t need, int32_t* error, double timeout_s, void* stream) {
+    if (!counter) return fail(STE_EINVAL, "counter is NULL");
+    hipLaunchKernelGGL(ste::sched_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)counter, (int)need, (int*)error,
+                       (unsigned long long)((timeout_s > 0 ? timeout_s : 2.0) * 1e8));
+    return check_hip(hipGetLastError(), "sched_gate launch");
 }
 
 int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream) {

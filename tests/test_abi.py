@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
 
     lib = binding.load()
     hdr = open(os.path.join(ROOT, "include", "ste.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(ste_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(ste_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed from include/ste.h"
     assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
     for name in declared:
@@ -27,12 +27,13 @@ def test_struct_layout_matches_header():
 
     hdr = open(os.path.join(ROOT, "include", "ste.h")).read()
     for cname, mirror in (("ste_ukf_batch_f64", binding.SteUkfBatchF64), ("ste_gp_batch_f64", binding.SteGpBatchF64),
-                          ("ste_prep_batch_f64", binding.StePrepBatchF64)):
+                          ("ste_prep_batch_f64", binding.StePrepBatchF64), ("ste_fwd_sched_f64", binding.SteFwdSchedF64)):
         body = hdr[hdr.index("typedef struct %s {" % cname): hdr.index("} %s;" % cname)]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|int64_t|double)\s*\*?\s*(\w+)\s*;", body)
+        fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|int64_t|double|size_t|void|ste_ukf_batch_f64)\s*\*?\s*(\w+)\s*;", body)
         assert fields == [f[0] for f in mirror._fields_], cname
     assert C.sizeof(binding.SteUkfBatchF64) == 24 + 3 * 8 + 22 * 8 + 16 + 8 + 8 + 8  # 0.3.1: track_stride, sm_pos, 2 x int32
+    assert C.sizeof(binding.SteFwdSchedF64) == 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # 0.3.2
 
 
 def _minimal_batch(binding, keep):
