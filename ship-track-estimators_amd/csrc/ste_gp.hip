@@ -286,6 +286,27 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
             }
     }
 }
+// One 16-k sub-block of the steady state with the shared fragments ROLLING: a[m] holds block row m of sub-block `sub` on
+// entry; after its sixteen MFMAs it is refilled with block row m of sub-block sub + 1 (kLast: the block's last sub-block,
+// nothing to fetch -- the next block's fragments lie in the other staging buffer, behind the barrier).
+template <bool kLast>
+__device__ __forceinline__ void mma_sub_rolling(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
+                                                v4d (&a)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+        if (!kLast) {
+            // (fenced on both sides: unfenced, hipcc hoists the reads to the top of the block or sinks them to their use)
+            __builtin_amdgcn_sched_barrier(0);
+            a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * (sub + 1) + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 // accT -= sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T (both callers subtract the product, so
 // the shared panel is negated once on its way into LDS).  `shared` points at row 0 / column 0
 // of the shared 64-row panel.  A wave's four own strips are 16 rows of FOUR DIFFERENT tiles (own[n] = strip `wave` of
@@ -316,14 +337,31 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         const int nlive = min(cap, kb - wb0 + 1);
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
         stage_load(st, shared + (size_t)kn, lds_ld, tid);
-        mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive, mcap);
-        load_rows(f0, own, kn);
-        mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive, mcap);
-        load_rows(f1, own, kn + 16);
-        mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive, mcap);
-        load_rows(f2, own, kn + 32);
-        mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive, mcap);
-        load_rows(f3, own, kn + 48);
+        if (kFull) {
+            // steady state (round 5): block row m of the shared fragment is refilled for the NEXT sub-block right behind its own
+            // sixteen MFMAs, so its LDS read has the other three block rows' 48 MFMAs to land in; before, all four rows were
+            // read and waited for in front of every sub-block's 64 MFMAs
+            v4d a[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(cur + (r + 16 * m) * LDB + 4 * g);
+            mma_sub_rolling<false>(acc, cur, 0, f0, r, g, a);
+            load_rows(f0, own, kn);
+            mma_sub_rolling<false>(acc, cur, 1, f1, r, g, a);
+            load_rows(f1, own, kn + 16);
+            mma_sub_rolling<false>(acc, cur, 2, f2, r, g, a);
+            load_rows(f2, own, kn + 32);
+            mma_sub_rolling<true>(acc, cur, 3, f3, r, g, a);
+            load_rows(f3, own, kn + 48);
+        } else {
+            mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive, mcap);
+            load_rows(f0, own, kn);
+            mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive, mcap);
+            load_rows(f1, own, kn + 16);
+            mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive, mcap);
+            load_rows(f2, own, kn + 32);
+            mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive, mcap);
+            load_rows(f3, own, kn + 48);
+        }
         stage_store(nxt, st, tid);
         __syncthreads();
     };
@@ -385,6 +423,44 @@ __device__ __forceinline__ void stage_half(double* dst, const double* src, size_
 }
 // (nlive is fixed for the pass here; kFull = all four strips live: the two cases are separate loops, because one loop with
 //  both bodies does not fit the 256 registers of two workgroups per CU)
+// Round 5: the shared fragment of block row m is read in two 16-byte halves (k = 4g, 4g+1 | 4g+2, 4g+3) that are refilled
+// in turn -- each half for the NEXT block row as soon as its eight MFMAs have been issued, while the other half's eight
+// run -- so that an LDS read always has 512 matrix-pipe cycles to land in.  Before, both halves were read and waited for
+// (s_waitcnt lgkmcnt(0)) in front of every group of sixteen MFMAs: ~130 exposed cycles per 1 024.  Same registers.
+struct HalfFrag {
+    v2d lo, hi;
+};
+__device__ __forceinline__ v2d frag_half(const double* blk, int sub, int m, int h, int r, int g) {
+    return *reinterpret_cast<const v2d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g + 2 * h);
+}
+// one 16-k sub-block of a full pass: 64 MFMAs, the fragment halves of (sub, m + 1) -- or (nsub_next, 0) after m = 3 --
+// fetched behind the halves in use
+template <bool kLast>
+__device__ __forceinline__ void mma_sub_lean_rolling(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r,
+                                                     int g, HalfFrag& a) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const bool more = m < 3 || !kLast;
+        const int ns = m < 3 ? sub : sub + 1, nm = m < 3 ? m + 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.lo[e], own.v[n][e], acc[m][n], 0, 0, 0);
+        // (scheduling barriers: left alone, hipcc hoists every LDS read of the block to its top -- ten fragments live at once,
+        //  800 spilled registers -- and a read that is merely fenced off from above sinks to the end of its region, right in
+        //  front of its use)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) a.lo = frag_half(blk, ns, nm, 0, r, g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi[e], own.v[n][2 + e], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) a.hi = frag_half(blk, ns, nm, 1, r, g);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 template <bool kFull>
 __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double* shared, size_t lds_ld,
                                                   const double* const (&own)[4], int kb0, int kb1, int nlive, int nsub,
@@ -405,18 +481,36 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
         // each half of the next panel block is fetched one sub-block before it is parked in LDS: fetched and parked in one go,
         // the wave sat through a whole memory latency twice per block (s_waitcnt vmcnt(0) right behind the loads)
         v4d st[2];
-        stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
-        mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
-        load_rows(f0, own, kb * T + 32);
-        stage_half_store(nxt, st, tid, 0);
-        stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 1);
-        if (4 * kb + 1 < nsub) mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
-        load_rows(f1, own, kb * T + 48);
-        if (4 * kb + 2 < nsub) mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
-        load_rows(f0, own, kn);
-        stage_half_store(nxt, st, tid, 1);
-        if (4 * kb + 3 < nsub) mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
-        load_rows(f1, own, kn + 16);
+        if (kFull) {
+            HalfFrag a;
+            a.lo = frag_half(cur, 0, 0, 0, r, g);
+            a.hi = frag_half(cur, 0, 0, 1, r, g);
+            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
+            mma_sub_lean_rolling<false>(acc, cur, 0, f0, r, g, a);
+            load_rows(f0, own, kb * T + 32);
+            stage_half_store(nxt, st, tid, 0);
+            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 1);
+            if (4 * kb + 1 < nsub) mma_sub_lean_rolling<false>(acc, cur, 1, f1, r, g, a);
+            load_rows(f1, own, kb * T + 48);
+            if (4 * kb + 2 < nsub) mma_sub_lean_rolling<false>(acc, cur, 2, f0, r, g, a);
+            load_rows(f0, own, kn);
+            stage_half_store(nxt, st, tid, 1);
+            if (4 * kb + 3 < nsub) mma_sub_lean_rolling<true>(acc, cur, 3, f1, r, g, a);
+            load_rows(f1, own, kn + 16);
+        } else {
+            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
+            mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
+            load_rows(f0, own, kb * T + 32);
+            stage_half_store(nxt, st, tid, 0);
+            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 1);
+            if (4 * kb + 1 < nsub) mma_sub_lean<kFull>(acc, cur, 1, f1, r, g, nlive);
+            load_rows(f1, own, kb * T + 48);
+            if (4 * kb + 2 < nsub) mma_sub_lean<kFull>(acc, cur, 2, f0, r, g, nlive);
+            load_rows(f0, own, kn);
+            stage_half_store(nxt, st, tid, 1);
+            if (4 * kb + 3 < nsub) mma_sub_lean<kFull>(acc, cur, 3, f1, r, g, nlive);
+            load_rows(f1, own, kn + 16);
+        }
         __syncthreads();
     }
 }
