@@ -61,7 +61,7 @@ BYTES_FWD = 192  # algorithmic, per track-step: 32 B inputs + 160 B filtered mea
 BYTES_BWD = 320  # algorithmic, per track-step: 160 B filtered history re-read + 160 B smoothed written
 FLOPS_NOMINAL = 2.0e4  # SURVEY.md §8d estimate of the REFERENCE algorithm (fp64 flop-equivalents, forward + backward)
 # rocprofv3 PMC summary of this command for the current kernel generation (see profiles/README.md for the passes)
-COUNTERS_CSV = os.path.join(ROOT, "profiles", "r04_counters_per_track_step.csv")
+COUNTERS_CSV = os.path.join(ROOT, "profiles", "r05_counters_per_track_step.csv")
 EVENT_EVERY = 4  # steps between two steps whose kernels are bracketed by HIP events (see the timed loop)
 
 

@@ -134,7 +134,7 @@ def measure(tracks=1000, nobs=2000, evals=3, cpu_evals=2, fit=False):
     if (B, n) == (1000, 2000):
         # HBM bytes of one batched objective from the committed rocprofv3 --pmc summary of this command (all kernels of the
         # objective; FETCH_SIZE doubled per the gfx950 calibration, profiles/README.md)
-        path = os.path.join(ROOT, "profiles", "r04_gp_counters_1000x2000.csv")
+        path = os.path.join(ROOT, "profiles", "r05_gp_counters_1000x2000.csv")
         try:
             import csv
 

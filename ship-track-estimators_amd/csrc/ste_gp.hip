@@ -255,6 +255,35 @@ __device__ __forceinline__ void stage_store(double* dst, const v4d (&st)[4], int
         *reinterpret_cast<v4d*>(dst + (e >> 4) * LDB + (e & 15) * 4) = -st[q];  // the panel is staged NEGATED
     }
 }
+// ---- the shared panel by LDS-DMA (gfx950 global_load_lds_dwordx4), -DSTE_GP_GLDS=1 -------------------------------------
+// One wave-instruction moves 64 x 16 B from per-lane global addresses to ONE contiguous KB of LDS (wave-uniform base in M0 +
+// 16 B x lane), so the staged block is kept in FRAGMENT order: chunk (sub, m, h) holds, for lane (r, g), the two doubles
+// k = 16 sub + 4 g + 2 h + {0, 1} of panel row 16 m + r -- exactly what that lane feeds MFMAs e = 2 h, 2 h + 1 of block row m.
+// Fragment reads are then two conflict-free ds_read_b128 of consecutive lanes.  No staging registers (32 per lane), no
+// ds_write, no negation pass: the MFMAs negate their A operand (neg:[1,0,0]).  Wave w fills the chunks of block row m = w
+// (its own 16 panel rows, whole 128-byte lines between its two halves).
+#ifndef STE_GP_GLDS
+#define STE_GP_GLDS 0
+#endif
+constexpr bool kGlds = STE_GP_GLDS != 0;
+constexpr int kChunk = 128;  // doubles per chunk (1 KB)
+__device__ __forceinline__ int chunk_of(int sub, int m, int h) { return ((sub * 4 + m) * 2 + h) * kChunk; }
+__device__ __forceinline__ void glds_panel_block(double* dst, const double* src_lane, int wave) {
+    // src_lane = panel + (16 wave + r) * ld + 4 g + k0 (this lane's row of its wave's block row, at the block's first k)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_global_load_lds(src_lane + 16 * sub + 2 * h, (lds_ptr)(dst + chunk_of(sub, wave, h)), 16, 0, 0);
+}
+__device__ __forceinline__ v4d frag_glds(const double* blk, int sub, int m, int lane) {
+    const v2d lo = *reinterpret_cast<const v2d*>(blk + chunk_of(sub, m, 0) + 2 * lane);
+    const v2d hi = *reinterpret_cast<const v2d*>(blk + chunk_of(sub, m, 1) + 2 * lane);
+    return v4d{lo[0], lo[1], hi[0], hi[1]};
+}
+constexpr int kNegA = kGlds ? 1 : 0;  // blgp of the f64 MFMA = neg modifiers: bit 0 negates A
+
 // acc[m][n] += shared[16 m + ..][k] * own_n[..][k] for one 16-k sub-block; shared fragments come from LDS.  Only the first
 // `nlive` of the wave's four own strips take part (4 in the steady state: one basic block of 64 MFMAs).
 template <bool kFull>
@@ -262,7 +291,8 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
                                         int nlive, int mcap) {
     v4d a[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
+    for (int m = 0; m < 4; ++m)
+        a[m] = kGlds ? frag_glds(blk, sub, m, r + 16 * g) : *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * sub + 4 * g);
     if (kFull) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -270,7 +300,7 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, kNegA);
     } else {
         // own strips n >= nlive and shared 16-row groups m >= mcap (the zero padding of the last panel) stay out
 #pragma unroll
@@ -281,7 +311,7 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
                     if (m < mcap) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, kNegA);
                     }
             }
     }
@@ -298,11 +328,12 @@ __device__ __forceinline__ void mma_sub_rolling(v4d (&acc)[4][4], const double* 
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, kNegA);
         if (!kLast) {
             // (fenced on both sides: unfenced, hipcc hoists the reads to the top of the block or sinks them to their use)
             __builtin_amdgcn_sched_barrier(0);
-            a[m] = *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * (sub + 1) + 4 * g);
+            a[m] = kGlds ? frag_glds(blk, sub + 1, m, r + 16 * g)
+                         : *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * (sub + 1) + 4 * g);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -321,13 +352,17 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
     if (kb0 >= kb1) return;
     const int r = lane & 15, g = lane >> 4;
     v4d st[4];
-    stage_load(st, shared + (size_t)kb0 * T, lds_ld, tid);
+    const double* panel_lane = shared + (size_t)(16 * (tid >> 6) + r) * lds_ld + 4 * g;  // kGlds: this lane's panel row
+    if (kGlds)
+        glds_panel_block(stage, panel_lane + (size_t)kb0 * T, tid >> 6);
+    else
+        stage_load(st, shared + (size_t)kb0 * T, lds_ld, tid);
     RowFrag f0, f1, f2, f3;
     load_rows(f0, own, kb0 * T);
     load_rows(f1, own, kb0 * T + 16);
     load_rows(f2, own, kb0 * T + 32);
     load_rows(f3, own, kb0 * T + 48);
-    stage_store(stage, st, tid);
+    if (!kGlds) stage_store(stage, st, tid);
     __syncthreads();
     auto block = [&](auto full, int kb) {
         constexpr bool kFull = decltype(full)::value;
@@ -336,14 +371,18 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         const bool more = kb + 1 < kb1;
         const int nlive = min(cap, kb - wb0 + 1);
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
-        stage_load(st, shared + (size_t)kn, lds_ld, tid);
+        if (kGlds)
+            glds_panel_block(nxt, panel_lane + (size_t)kn, tid >> 6);  // nxt was last read in the previous block: free since its barrier
+        else
+            stage_load(st, shared + (size_t)kn, lds_ld, tid);
         if (kFull) {
             // steady state (round 5): block row m of the shared fragment is refilled for the NEXT sub-block right behind its own
             // sixteen MFMAs, so its LDS read has the other three block rows' 48 MFMAs to land in; before, all four rows were
             // read and waited for in front of every sub-block's 64 MFMAs
             v4d a[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4d*>(cur + (r + 16 * m) * LDB + 4 * g);
+            for (int m = 0; m < 4; ++m)
+                a[m] = kGlds ? frag_glds(cur, 0, m, lane) : *reinterpret_cast<const v4d*>(cur + (r + 16 * m) * LDB + 4 * g);
             mma_sub_rolling<false>(acc, cur, 0, f0, r, g, a);
             load_rows(f0, own, kn);
             mma_sub_rolling<false>(acc, cur, 1, f1, r, g, a);
@@ -362,7 +401,7 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
             mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive, mcap);
             load_rows(f3, own, kn + 48);
         }
-        stage_store(nxt, st, tid);
+        if (!kGlds) stage_store(nxt, st, tid);
         __syncthreads();
     };
     // Two loops, not one with both bodies: with the partial and the full MFMA sequences in one loop the accumulators of the
