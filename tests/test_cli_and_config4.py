@@ -453,7 +453,9 @@ def test_bench_line_carries_the_contract():
     assert abs(r["achieved"] - 512 * out["value"] / 1e9) < 1e-6 * r["achieved"] and r["algorithmic_bytes_per_track_step"] == 512
     pl = r["per_launch"]  # one launch of the dominant kernel over its own HIP-event duration
     assert pl["kernel"] == "ukf_forward" and pl["launch_ms"] > 0 and pl["launches_in_flight"] >= 1
-    assert abs(pl["achieved"] - 192 * 640 * 500 / (pl["launch_ms"] * 1e-3) / 1e9) < 1e-6 * pl["achieved"]
+    # (30 steps: bench.py --sequence auto runs the forward passes as scheduled launches of 10 steps each)
+    assert pl["steps_per_launch"] == 10 and out["config"]["steps_per_scheduled_forward_launch"] == 10
+    assert abs(pl["achieved"] - 192 * 640 * 500 * pl["steps_per_launch"] / (pl["launch_ms"] * 1e-3) / 1e9) < 1e-6 * pl["achieved"]
     fl = out["extra"]["fleet_100k"]  # the product entry point for a fleet, on a small one here
     assert fl["bit_identical_to_one_launch"] is True and fl["track_steps"] == 1500 * 500 and fl["value"] > 0
     assert fl["gpu_vs_oracle"]["means_smoothed_max_rel_err"] < 1e-6 and fl["flagged_tracks"] == 0
