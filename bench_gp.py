@@ -51,7 +51,7 @@ def wiggle_tracks(B, n, seed=0):
     return xs, ys
 
 
-def measure_fit(tracks=64, nobs=2000, restarts=15, cpu=True):
+def measure_fit(tracks=64, nobs=2000, restarts=15, cpu=True, lockstep_only=False):
     """A whole hyper-parameter fit the way the reference asks for it (L-BFGS-B from the example's kernel plus seeded
     restarts, best optimum kept) on data with an interior optimum: all (restarts + 1) x tracks optimisers in lock-step
     as one batch, beside the same fit with the restarts one after the other and scikit-learn's fit of one track."""
@@ -64,7 +64,7 @@ def measure_fit(tracks=64, nobs=2000, restarts=15, cpu=True):
     theta0 = np.log([1.0, 1.0, 0.5])  # 1.0 * RBF(1.0) + WhiteKernel(0.5), the reference example's kernel
     bounds = np.log(np.tile([1e-5, 1e5], (3, 1)))
     out = {"tracks": tracks, "nobs": nobs, "restarts": restarts}
-    for label, cap in (("lockstep_all_restarts", gpm.MAX_LOCKSTEP_ENTRIES), ("restarts_one_after_the_other", 1)):
+    for label, cap in (("lockstep_all_restarts", gpm.MAX_LOCKSTEP_ENTRIES), ("restarts_one_after_the_other", 1))[:1 if lockstep_only else 2]:
         saved = gpm.MAX_LOCKSTEP_ENTRIES
         gpm.MAX_LOCKSTEP_ENTRIES = cap
         try:
@@ -224,9 +224,13 @@ def main():
                     help="instead: time a fit WITH this many restarts (run as extra batch entries) of --fit-tracks tracks x "
                          "--nobs observations on data with an interior optimum")
     ap.add_argument("--fit-tracks", type=int, default=64)
+    ap.add_argument("--fit-lockstep-only", action="store_true", help="--fit-restarts: skip the restart-by-restart comparison run")
+    ap.add_argument("--fit-no-cpu", action="store_true", help="--fit-restarts: skip scikit-learn's fit of one track on the host")
     a = ap.parse_args()
     if a.fit_restarts is not None:
-        print(json.dumps({"metric": "GP fit with restarts (tracks/s)", "fit": measure_fit(a.fit_tracks, a.nobs, a.fit_restarts)}))
+        print(json.dumps({"metric": "GP fit with restarts (tracks/s)",
+                          "fit": measure_fit(a.fit_tracks, a.nobs, a.fit_restarts, cpu=not a.fit_no_cpu,
+                                             lockstep_only=a.fit_lockstep_only)}))
         return
     print(json.dumps(measure(a.tracks, a.nobs, a.evals, a.cpu_evals, a.fit)))
 
