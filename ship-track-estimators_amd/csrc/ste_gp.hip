@@ -241,6 +241,13 @@ __device__ __forceinline__ void load_rows(RowFrag& f, const double* const (&pr)[
 #pragma unroll
     for (int n = 0; n < 4; ++n) f.v[n] = *reinterpret_cast<const v4d*>(pr[n] + k);
 }
+// only the first `nl` strips (wave-uniform): the strips of a pass's triangle that have not joined yet are structurally zero
+// or not yet written -- gp_trtri_cols moves 4.97 TB/s, and a sixth of its own-row fetches were of such strips
+__device__ __forceinline__ void load_rows_live(RowFrag& f, const double* const (&pr)[4], int k, int nl) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        if (n < nl) f.v[n] = *reinterpret_cast<const v4d*>(pr[n] + k);
+}
 __device__ __forceinline__ void stage_load(v4d (&st)[4], const double* src, size_t ld, int tid) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -319,9 +326,14 @@ __device__ __forceinline__ void mma_sub(v4d (&acc)[4][4], const double* blk, int
 // One 16-k sub-block of the steady state with the shared fragments ROLLING: a[m] holds block row m of sub-block `sub` on
 // entry; after its sixteen MFMAs it is refilled with block row m of sub-block sub + 1 (kLast: the block's last sub-block,
 // nothing to fetch -- the next block's fragments lie in the other staging buffer, behind the barrier).
-template <bool kLast>
+// The wave's own rows ride along the same way: strip m of the fragment set the PREVIOUS sub-block used (`refill`) is fetched
+// for its next use (16-k offset `refill_k`) behind block row m's MFMAs -- two 16-byte loads per sixteen MFMAs instead of
+// eight loads in a row between two sub-blocks, where each load's issue slot beyond the first MFMA's shadow is a matrix-pipe
+// bubble.
+template <bool kLast, typename Extra>
 __device__ __forceinline__ void mma_sub_rolling(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r, int g,
-                                                v4d (&a)[4]) {
+                                                v4d (&a)[4], RowFrag& refill, const double* const (&rows)[4], int refill_k,
+                                                Extra extra) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -329,13 +341,14 @@ __device__ __forceinline__ void mma_sub_rolling(v4d (&acc)[4][4], const double* 
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][e], own.v[n][e], acc[m][n], 0, 0, kNegA);
-        if (!kLast) {
-            // (fenced on both sides: unfenced, hipcc hoists the reads to the top of the block or sinks them to their use)
-            __builtin_amdgcn_sched_barrier(0);
+        // (fenced on both sides: unfenced, hipcc hoists the reads to the top of the block or sinks them to their use)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!kLast)
             a[m] = kGlds ? frag_glds(blk, sub + 1, m, r + 16 * g)
                          : *reinterpret_cast<const v4d*>(blk + (r + 16 * m) * LDB + 16 * (sub + 1) + 4 * g);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        refill.v[m] = *reinterpret_cast<const v4d*>(rows[m] + refill_k);
+        extra(m);  // (the caller's share of the same slot: a quarter of the next panel block's staging loads)
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // accT -= sum over 64-k blocks [kb0, kb1) of shared_rows[.][k] * own_rows[.][k]^T (both callers subtract the product, so
@@ -357,11 +370,14 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         glds_panel_block(stage, panel_lane + (size_t)kb0 * T, tid >> 6);
     else
         stage_load(st, shared + (size_t)kb0 * T, lds_ld, tid);
+    // fragment sets f0, f1, f2 hold sub-blocks 0-2 of the block about to run; f3 (sub-block 3) is fetched during sub-block 0
     RowFrag f0, f1, f2, f3;
-    load_rows(f0, own, kb0 * T);
-    load_rows(f1, own, kb0 * T + 16);
-    load_rows(f2, own, kb0 * T + 32);
-    load_rows(f3, own, kb0 * T + 48);
+    {
+        const int nl0 = min(cap, kb0 - wb0 + 1);
+        load_rows_live(f0, own, kb0 * T, nl0);
+        load_rows_live(f1, own, kb0 * T + 16, nl0);
+        load_rows_live(f2, own, kb0 * T + 32, nl0);
+    }
     if (!kGlds) stage_store(stage, st, tid);
     __syncthreads();
     auto block = [&](auto full, int kb) {
@@ -373,7 +389,7 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
         const int kn = (more ? kb + 1 : kb0) * T;  // the refills past the end re-read the first block and are dropped
         if (kGlds)
             glds_panel_block(nxt, panel_lane + (size_t)kn, tid >> 6);  // nxt was last read in the previous block: free since its barrier
-        else
+        else if (!kFull)
             stage_load(st, shared + (size_t)kn, lds_ld, tid);
         if (kFull) {
             // steady state (round 5): block row m of the shared fragment is refilled for the NEXT sub-block right behind its own
@@ -383,25 +399,39 @@ __device__ __forceinline__ void panel_gemm_t(v4d (&acc)[4][4], const double* sha
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 a[m] = kGlds ? frag_glds(cur, 0, m, lane) : *reinterpret_cast<const v4d*>(cur + (r + 16 * m) * LDB + 4 * g);
-            mma_sub_rolling<false>(acc, cur, 0, f0, r, g, a);
-            load_rows(f0, own, kn);
-            mma_sub_rolling<false>(acc, cur, 1, f1, r, g, a);
-            load_rows(f1, own, kn + 16);
-            mma_sub_rolling<false>(acc, cur, 2, f2, r, g, a);
-            load_rows(f2, own, kn + 32);
-            mma_sub_rolling<true>(acc, cur, 3, f3, r, g, a);
-            load_rows(f3, own, kn + 48);
+            // the next panel block's staging loads (register path) go a quarter each behind sub-block 0's block rows
+            const double* stage_src = shared + (size_t)kn;
+            auto stage_piece = [&](int q) {
+                if (!kGlds) {
+                    const int e = tid + 256 * q;
+                    st[q] = *reinterpret_cast<const v4d*>(stage_src + (size_t)(e >> 4) * lds_ld + (e & 15) * 4);
+                }
+            };
+            // ... and are parked (negated) in the other staging buffer a quarter each behind sub-block 3's block rows: that
+            // buffer was last read in the previous block, i.e. before the barrier every wave has passed since
+            auto park_piece = [&](int q) {
+                if (!kGlds) {
+                    const int e = tid + 256 * q;
+                    *reinterpret_cast<v4d*>(nxt + (e >> 4) * LDB + (e & 15) * 4) = -st[q];
+                }
+            };
+            auto nothing = [](int) {};
+            mma_sub_rolling<false>(acc, cur, 0, f0, r, g, a, f3, own, kb * T + 48, stage_piece);
+            mma_sub_rolling<false>(acc, cur, 1, f1, r, g, a, f0, own, kn, nothing);
+            mma_sub_rolling<false>(acc, cur, 2, f2, r, g, a, f1, own, kn + 16, nothing);
+            mma_sub_rolling<true>(acc, cur, 3, f3, r, g, a, f2, own, kn + 32, park_piece);
         } else {
+            const int nlive_next = min(cap, kb + 1 - wb0 + 1);  // strips live in the block these refills are for
+            load_rows_live(f3, own, kb * T + 48, nlive);
             mma_sub<kFull>(acc, cur, 0, f0, r, g, nlive, mcap);
-            load_rows(f0, own, kn);
+            load_rows_live(f0, own, kn, nlive_next);
             mma_sub<kFull>(acc, cur, 1, f1, r, g, nlive, mcap);
-            load_rows(f1, own, kn + 16);
+            load_rows_live(f1, own, kn + 16, nlive_next);
             mma_sub<kFull>(acc, cur, 2, f2, r, g, nlive, mcap);
-            load_rows(f2, own, kn + 32);
+            load_rows_live(f2, own, kn + 32, nlive_next);
             mma_sub<kFull>(acc, cur, 3, f3, r, g, nlive, mcap);
-            load_rows(f3, own, kn + 48);
         }
-        if (!kGlds) stage_store(nxt, st, tid);
+        if (!kGlds && !kFull) stage_store(nxt, st, tid);
         __syncthreads();
     };
     // Two loops, not one with both bodies: with the partial and the full MFMA sequences in one loop the accumulators of the
