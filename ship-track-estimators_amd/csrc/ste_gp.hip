@@ -504,9 +504,12 @@ __device__ __forceinline__ v2d frag_half(const double* blk, int sub, int m, int 
 }
 // one 16-k sub-block of a full pass: 64 MFMAs, the fragment halves of (sub, m + 1) -- or (nsub_next, 0) after m = 3 --
 // fetched behind the halves in use
-template <bool kLast>
+// slot(j), j = 0 .. 7: the caller's loads and stores for this sub-block, one behind every group of eight MFMAs (own-row
+// refills in the first four, a quarter of the next panel block's staging in the last four) instead of in a run between two
+// sub-blocks
+template <bool kLast, typename Slot>
 __device__ __forceinline__ void mma_sub_lean_rolling(v4d (&acc)[4][4], const double* blk, int sub, const RowFrag& own, int r,
-                                                     int g, HalfFrag& a) {
+                                                     int g, HalfFrag& a, Slot slot) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const bool more = m < 3 || !kLast;
@@ -520,6 +523,7 @@ __device__ __forceinline__ void mma_sub_lean_rolling(v4d (&acc)[4][4], const dou
         //  front of its use)
         __builtin_amdgcn_sched_barrier(0);
         if (more) a.lo = frag_half(blk, ns, nm, 0, r, g);
+        slot(2 * m);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -527,6 +531,7 @@ __device__ __forceinline__ void mma_sub_lean_rolling(v4d (&acc)[4][4], const dou
             for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.hi[e], own.v[n][2 + e], acc[m][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) a.hi = frag_half(blk, ns, nm, 1, r, g);
+        slot(2 * m + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -540,7 +545,7 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
     stage_half(stage, shared + (size_t)kb0 * T, lds_ld, tid, 1);
     RowFrag f0, f1;
     load_rows(f0, own, kb0 * T);
-    load_rows(f1, own, kb0 * T + 16);
+    if (!kFull) load_rows(f1, own, kb0 * T + 16);  // (the full loop fetches sub-block 1's rows during sub-block 0)
     __syncthreads();
     for (int kb = kb0; kb < kb1; ++kb) {
         double* cur = stage + ((kb - kb0) & 1) * (T * LDB);
@@ -554,18 +559,33 @@ __device__ __forceinline__ void panel_gemm_t_lean(v4d (&acc)[4][4], const double
             HalfFrag a;
             a.lo = frag_half(cur, 0, 0, 0, r, g);
             a.hi = frag_half(cur, 0, 0, 1, r, g);
-            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
-            mma_sub_lean_rolling<false>(acc, cur, 0, f0, r, g, a);
-            load_rows(f0, own, kb * T + 32);
-            stage_half_store(nxt, st, tid, 0);
-            stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 1);
-            if (4 * kb + 1 < nsub) mma_sub_lean_rolling<false>(acc, cur, 1, f1, r, g, a);
-            load_rows(f1, own, kb * T + 48);
-            if (4 * kb + 2 < nsub) mma_sub_lean_rolling<false>(acc, cur, 2, f0, r, g, a);
-            load_rows(f0, own, kn);
-            stage_half_store(nxt, st, tid, 1);
-            if (4 * kb + 3 < nsub) mma_sub_lean_rolling<true>(acc, cur, 3, f1, r, g, a);
-            load_rows(f1, own, kn + 16);
+            // Round 5: every load and store of the block sits behind a group of eight MFMAs.  During sub-block s the fragment
+            // set the sub-block before it used is refilled for sub-block s + 1 (slots 0-3: two whole sub-block halves of cover);
+            // the next panel block is staged in two halves, fetched in slots 4-5 of sub-blocks 0 / 2 and parked in slots 4-5 of
+            // sub-blocks 1 / 3.
+            const double* stage_src = shared + (size_t)kn;
+            auto refill = [&](RowFrag& f, int k, int j) {
+                if (j < 4) f.v[j] = *reinterpret_cast<const v4d*>(own[j] + k);
+            };
+            auto fetch = [&](int half, int j) {
+                if (j == 4 || j == 5) {
+                    const int e = tid + 256 * (2 * half + (j - 4));
+                    st[j - 4] = *reinterpret_cast<const v4d*>(stage_src + (size_t)(e >> 4) * lds_ld + (e & 15) * 4);
+                }
+            };
+            auto park = [&](int half, int j) {
+                if (j == 4 || j == 5) {
+                    const int e = tid + 256 * (2 * half + (j - 4));
+                    *reinterpret_cast<v4d*>(nxt + (e >> 4) * LDB + (e & 15) * 4) = -st[j - 4];
+                }
+            };
+            mma_sub_lean_rolling<false>(acc, cur, 0, f0, r, g, a, [&](int j) { refill(f1, kb * T + 16, j); fetch(0, j); });
+            if (4 * kb + 1 < nsub)
+                mma_sub_lean_rolling<false>(acc, cur, 1, f1, r, g, a, [&](int j) { refill(f0, kb * T + 32, j); park(0, j); });
+            if (4 * kb + 2 < nsub)
+                mma_sub_lean_rolling<false>(acc, cur, 2, f0, r, g, a, [&](int j) { refill(f1, kb * T + 48, j); fetch(1, j); });
+            if (4 * kb + 3 < nsub)
+                mma_sub_lean_rolling<true>(acc, cur, 3, f1, r, g, a, [&](int j) { refill(f0, kn, j); park(1, j); });
         } else {
             stage_half_load(st, shared + (size_t)kn, lds_ld, tid, 0);
             mma_sub_lean<kFull>(acc, cur, 0, f0, r, g, nlive);
