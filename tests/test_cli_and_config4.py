@@ -387,6 +387,14 @@ def test_bench_two_rank_control_flow():
     assert res.returncode == 0, res.stderr[-2000:]
     out2 = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out2["config"]["gather_every"] == 2 and "once per 2 steps" in out2["config"]["parallelism"] and out2["value"] > 0
+    # the exchange behind SCHEDULED forward launches (bench.py --sequence N; not the default with more than one rank): the
+    # all-gather hook of every step goes behind that step's smoother on its gated smoother stream
+    cmd3 = cmd[:cmd.index("29533")] + ["29535"] + cmd[cmd.index("29533") + 1:] + ["--sequence", "2"]
+    res = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out3 = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out3["config"]["steps_per_scheduled_forward_launch"] == 2 and out3["status_flagged_tracks"] == 0 and out3["value"] > 0
+    assert out["config"]["steps_per_scheduled_forward_launch"] == 0  # auto: per-step launches when ranks exchange
 
 
 @pytest.mark.gpu
