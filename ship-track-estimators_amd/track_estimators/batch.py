@@ -905,6 +905,18 @@ class SmootherPipeline:
             if key in seen:
                 raise ValueError("submit_sequence: every batch of a sequence needs histories of its own (a buffer set appears twice)")
             seen.add(key)
+        if len(self._sched_live) > 8:
+            # a caller that never synchronises the pipeline: retire the launches that have long finished (their tables and
+            # counters are only kept for the error word, which is looked at now)
+            finished = lambda e: all(ev.query() for ev in e[5] + e[6])  # noqa: E731
+            done_ones = [e for e in self._sched_live if finished(e)]
+            if done_ones:
+                keep = [e for e in self._sched_live if not any(e is d for d in done_ones)]
+                self._sched_live = done_ones
+                try:
+                    self._check_scheduled()
+                finally:
+                    self._sched_live = keep
         k = self._count
         self._count += 1
         fwd_stream = self.fwd_streams[k % len(self.fwd_streams)]
@@ -956,9 +968,10 @@ class SmootherPipeline:
             timing["forward"][1].record(fwd_stream)
         ready = torch.cuda.Event()
         ready.record(fwd_stream)
-        # the launch's tables and counters stay alive until the pipeline is synchronised (their error word is read then)
-        self._sched_live.append((host_ws, dev_ws, counters, structs, items, ready))
+        # the launch's tables and counters stay alive until the pipeline is synchronised, or every gate and smoother that
+        # looks at them has finished (their error word is read then)
         events = []
+        self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events))
         waited = set()
         for i, db in enumerate(dbs):
             if getattr(db, "_pipeline_done", None) is None:
@@ -995,7 +1008,7 @@ class SmootherPipeline:
     def _check_scheduled(self):
         """After a synchronisation: the error words of the scheduled launches issued since the last one."""
         live, self._sched_live = self._sched_live, []
-        bad = [int(c[-1].item()) for _h, _d, c, _s, _i, _r in live]
+        bad = [int(e[2][-1].item()) for e in live]
         if any(bad):
             raise binding.SteError("a scheduled forward launch could not progress (error word %s: 1 = a forward wave, 2 = a smoother "
                                    "gate waited longer than its bound); results of that sequence are incomplete" % bad)
