@@ -214,3 +214,38 @@ def test_scheduled_fleet_with_clamped_priors_and_recorded_noise_is_bit_identical
     db2 = _clear(batch.DeviceBatch(hb))
     batch.run_fleet(db2, chunk=256)
     assert _same(db, db2) and np.array_equal(res["status"], ref.status_host())
+
+
+@pytest.mark.gpu
+def test_slices_that_change_waves_every_round_hand_over_bit_for_bit():
+    """The list scheduler keeps a running tile on its wave, so the in-kernel hand-over between waves (release of the history
+    row, work rows, status and first-bad word at agent scope; acquire by the next slice -- possibly on another XCD) is
+    exercised only by pre-empted tiles.  Here the table is rotated by a different amount every round: EVERY slice of every
+    tile runs on another wave than the one before it, twenty times over, and the results must stay those of plain launches."""
+    import torch
+
+    _, hb = _uniform(6000, 4_100_000, nobs=81, substeps=4)  # 94 tiles x 5 slices per batch
+    hb.lanes = 1
+    ref = _clear(batch.DeviceBatch(hb))
+    ref.run()
+    torch.cuda.synchronize()
+    seqs = [_clear(batch.DeviceBatch(hb)) for _ in range(3)]
+    with batch.SmootherPipeline(ntracks=6000) as pipe:
+        ntiles, nslices = [94] * 3, [5] * 3
+        nwaves = 4 * (pipe.forward_cus - pipe.reserve_cus)
+        items = batch.forward_schedule(ntiles, nslices, nwaves).copy()
+        for r in range(items.shape[0]):
+            items[r] = np.roll(items[r], 131 * (r + 1), axis=0)  # 131 waves = 32 compute units and a bit: another XCD, usually
+        moved = 0
+        for r in range(1, items.shape[0]):
+            prev = {tuple(v): i for i, v in enumerate(items[r - 1]) if v[0] >= 0}
+            moved += sum(1 for i, v in enumerate(items[r]) if v[0] >= 0 and prev.get(tuple(v), i) != i)
+        assert moved >= 3 * 94 * 4  # every hand-over crosses waves
+        pipe._schedules[(tuple(ntiles), tuple(nslices), nwaves, 0.0)] = np.ascontiguousarray(items)
+        for rep in range(20):
+            for d in seqs:
+                _clear(d)
+            pipe.submit_sequence(seqs)
+            pipe.synchronize()
+            for d in seqs:
+                assert _same(ref, d), rep
