@@ -393,8 +393,8 @@ def _main(stack):
                     help="steps per SCHEDULED forward launch (SmootherPipeline.submit_sequence: the forward passes of that many "
                          "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
                          "step, or 'auto' = 10 when --steps <= 40 (a short run is all fill and drain, which the schedule "
-                         "shortens: 0.77 against 0.80 ms per step at the driver's 20 steps), 0 for longer runs (in the steady "
-                         "state per-step launches re-balance by themselves and are 2-4 %% faster; DESIGN.md section 5)")
+                         "shortens: 0.75 against 0.80 ms per step at the driver's 20 steps), 0 for longer runs (in the steady "
+                         "state per-step launches re-balance by themselves and are 1-2 %% faster; DESIGN.md section 5)")
     ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
     ap.add_argument("--fleet-tracks", type=int, default=100_000)
     ap.add_argument("--fleet-chunk", type=int, default=None, help="window size of the fleet entry (default: batch.FLEET_CHUNK)")
@@ -541,7 +541,7 @@ def _main(stack):
             return
         for c0 in range(0, nsteps, seq):
             ks = list(range(c0, min(c0 + seq, nsteps)))
-            tm = {} if events is not None else None
+            tm = {"every": EVENT_EVERY} if events is not None else None
             hook = None
             if gathered is not None:
                 def hook(i, _s, ks=ks):  # noqa: E306
@@ -759,7 +759,7 @@ def _main(stack):
                            "timed_launches": len(seq_timings) if seq else len([e for e in evs if e is not None]),
                            "steps_per_forward_launch": steps_per_launch,
                            "note": ("HIP events around every scheduled forward launch (the forward passes of "
-                                    f"{steps_per_launch:g} steps each) and around every step's smoother" if seq else
+                                    f"{steps_per_launch:g} steps each) and around the smoother of every {EVENT_EVERY}th step" if seq else
                                     f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region")},
             "steady_state": steady,
             "all_gather_alone": gather_alone,

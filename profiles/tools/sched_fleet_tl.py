@@ -28,7 +28,7 @@ for chunk in (16384, 10048):
             t3 = time.perf_counter() - t0
             print(f'chunk {chunk} forward only: scheduled {t1*1e3:.3f}  per-window {t2*1e3:.3f}  one launch {t3*1e3:.3f} ms', flush=True)
         for rep in range(2):
-            tm = {}
+            tm = {"every": 1}
             torch.cuda.synchronize(); t0 = time.perf_counter()
             pipe.submit_sequence(ws, timing=tm); pipe.synchronize()
             t1 = time.perf_counter() - t0

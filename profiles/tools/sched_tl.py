@@ -25,7 +25,7 @@ with batch.SmootherPipeline(dev, ntracks=B) as pipe:
         t2 = time.perf_counter() - t0
         print(f'forward only K={K}: scheduled {t1*1e3:.3f} ms  per-batch {t2*1e3:.3f} ms', flush=True)
     for rep in range(2):
-        tm = {}
+        tm = {"every": 1}
         torch.cuda.synchronize(); t0 = time.perf_counter()
         pipe.submit_sequence(dbs, timing=tm, stagger=stag); pipe.synchronize()
         t1 = time.perf_counter() - t0

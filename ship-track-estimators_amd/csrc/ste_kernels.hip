@@ -822,14 +822,16 @@ __device__ __forceinline__ void forward_tile_l1(const KParams& p, const size_t t
     }
     store_hist(p, 0, B, t, x, P);  // slot 0 = prior (kalman_filter.py:76-77); a later slice rewrites row k0 with its own bits
 
-    int st = cont ? (p.status[t] & ~STE_STATUS_NAN) : 0;  // the NaN bit is taken from the final state, as in a whole pass
+    // (a later slice may run in the same launch, on the same wave, as the one that wrote these two words -- the scheduled
+    //  kernel -- without a cache invalidate in between: read them past the CU's L1)
+    int st = cont ? (__hip_atomic_load(&p.status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~STE_STATUS_NAN) : 0;  // the NaN bit is taken from the final state, as in a whole pass
     const bool initial_update = !(p.flags & STE_FLAG_NO_INITIAL_UPDATE);
     const bool noise_mode = p.noise_pred || p.noise_upd || p.noise_rts;
     bool flagged = false;  // sticky: a square root of this track was clamped or did not converge
     double* first_bad = (kGains && p.rts_work) ? p.first_bad + t : nullptr;
     if (first_bad) {
         if (cont)
-            flagged = *first_bad != kNeverBad;
+            flagged = __hip_atomic_load(first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kNeverBad;
         else
             *first_bad = kNeverBad;
     }
@@ -934,10 +936,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // (ste_stream_wait_counter: a one-wave gate kernel on the smoother's stream).
 // ---------------------------------------------------------------------------------------------------------------
 struct SchedItem {
-    int kp;    // index into the KParams table (one entry per (window, slice)), < 0: nothing to do this round
-    int tile;  // 64-track tile of that window
+    int kp;    // index into the KParams table (one entry per (window, run of slices)), < 0: nothing to do this round
+    int tile;  // 64-track tile of that window | slices of the tile done once this item has run << 24
     int prog;  // index of the tile's progress counter
-    int meta;  // slice | last-slice flag << 8 | window << 9
+    int meta;  // slice | last-slice flag << 8 | window << 9 (22 bits) | hand-over flags: bit 31 = the slice before this one ran
+               // on ANOTHER wave (wait for the tile's count and acquire), bit 30 = the next slice runs on another wave, or there is
+               // none (release and publish).  A tile that stays on its wave -- the rule -- needs neither: a wave sees its own stores.
 };
 struct SchedParams {
     const KParams* kps;
@@ -970,24 +974,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const SchedItem* ip = sp.items + ((size_t)r * sp.nwaves + blockIdx.x);
         const int kp = __builtin_amdgcn_readfirstlane(ip->kp);
         if (kp < 0) continue;
-        const int tile = __builtin_amdgcn_readfirstlane(ip->tile), prog = __builtin_amdgcn_readfirstlane(ip->prog);
+        const int tile_word = __builtin_amdgcn_readfirstlane(ip->tile), prog = __builtin_amdgcn_readfirstlane(ip->prog);
+        const int tile = tile_word & 0xffffff, publish = (tile_word >> 24) & 0xff;  // publish: slices done once this item has run
         const int meta = __builtin_amdgcn_readfirstlane(ip->meta);
         const int slice = meta & 0xff;
-        if (__hip_atomic_load(sp.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-        if (slice > 0 && !sched_wait(sp.progress + prog, slice, sp.timeout_ticks)) {
+        // (the error word is looked at only where a wave waits: a launch that cannot progress ends through its bounded waits)
+        if (meta < 0 && (__hip_atomic_load(sp.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                         !sched_wait(sp.progress + prog, slice, sp.timeout_ticks))) {
             if (threadIdx.x == 0) __hip_atomic_store(sp.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         const KParams& p = *(const KParams*)(ConstKParams*)(uintptr_t)(sp.kps + kp);
         if (threadIdx.x == 0) *(volatile int*)&g_sched_word[0] = p.k0;
         forward_tile_l1<kGains, kFastUpd, kRobust, true>(p, (size_t)tile * 64 + threadIdx.x);
-        // publish: this wave's stores have been acknowledged, then made visible at agent scope, before the count moves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(sp.progress + prog, slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (meta & 0x100) __hip_atomic_fetch_add(sp.window_done + (meta >> 9), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (meta & 0x40000000) {
+            // publish: this wave's stores have been acknowledged, then made visible at agent scope, before the count moves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(sp.progress + prog, publish, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (meta & 0x100)
+                    __hip_atomic_fetch_add(sp.window_done + ((meta >> 9) & 0x1fffff), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -2562,7 +2571,9 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream) {
 size_t ste_ukf_forward_sched_workspace(int32_t nwindows, int32_t max_slices, int64_t ntiles_total, int32_t nrounds,
                                        int32_t nwaves) {
     if (nwindows < 0 || max_slices < 0 || ntiles_total < 0 || nrounds < 0 || nwaves < 0) return 0;
-    return sched_layout((size_t)nwindows * (size_t)max_slices, (size_t)nrounds * (size_t)nwaves, (size_t)ntiles_total).total;
+    // a parameter block per (window, run of consecutive slices): max_slices (max_slices + 1) / 2 of them per window
+    return sched_layout((size_t)nwindows * ((size_t)max_slices * ((size_t)max_slices + 1) / 2), (size_t)nrounds * (size_t)nwaves,
+                        (size_t)ntiles_total).total;
 }
 
 int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
@@ -2574,7 +2585,7 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
     const int step = sc->slice_steps ? sc->slice_steps : STE_SLICE_ALIGN;
     if (step < STE_SLICE_ALIGN || step % STE_SLICE_ALIGN != 0)
         return fail(STE_EINVAL, "scheduled forward pass: slice_steps must be a positive multiple of STE_SLICE_ALIGN (64)");
-    if (sc->nwindows >= (1 << 22)) return fail(STE_EINVAL, "scheduled forward pass: too many windows");
+    if (sc->nwindows >= (1 << 21)) return fail(STE_EINVAL, "scheduled forward pass: too many windows");
     // per window: slices, tiles, and where its KParams and progress counters start
     std::vector<int> nslices((size_t)sc->nwindows), kp0((size_t)sc->nwindows), tile0((size_t)sc->nwindows + 1);
     size_t nkp = 0, ntiles = 0;
@@ -2589,7 +2600,7 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
         max_slices = std::max(max_slices, nslices[w]);
         kp0[w] = (int)nkp;
         tile0[w] = (int)ntiles;
-        nkp += (size_t)nslices[w];
+        nkp += (size_t)nslices[w] * ((size_t)nslices[w] + 1) / 2;  // one per run of slices [q0, q1], q0 <= q1
         ntiles += ((size_t)b.B + 63) / 64;
         if (ntiles > 0x7fffffff) return fail(STE_EINVAL, "scheduled forward pass: too many tiles");
     }
@@ -2599,28 +2610,35 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
     if (sc->ws_bytes < lay.total) return fail(STE_EINVAL, "scheduled forward pass: workspace too small (ste_ukf_forward_sched_workspace)");
     char* hw = (char*)sc->host_ws;
     ste::KParams* kps = (ste::KParams*)(hw + lay.kps);
+    // parameter block of window w for the run of slices [q0, q1]: built when a (merged) item first needs it
     int variant = -1;
-    for (int w = 0; w < sc->nwindows; ++w) {
-        for (int q = 0; q < nslices[w]; ++q) {
-            ste_ukf_batch_f64 b = sc->windows[w];
-            b.flags |= STE_FLAG_LANES_1;
-            b.step_begin = q * step;
-            b.step_end = std::min(b.Nmax, (q + 1) * step);
-            ste::KParams* kp = kps + kp0[w] + q;
-            int rc = make_params(&b, false, false, kp);
-            if (rc) return rc;
-            rc = slice_params(&b, kp);
-            if (rc) return rc;
-            const int v = forward_variant(*kp);
-            if (variant >= 0 && v != variant)
-                return fail(STE_EINVAL, "scheduled forward pass: the windows must agree on H / R structure, robust flag and rts_work (one kernel runs them all)");
-            variant = v;
-        }
-    }
+    std::vector<char> have(nkp, 0);
+    auto run_index = [&](int w, int q0, int q1) { return kp0[w] + q0 * nslices[w] - q0 * (q0 - 1) / 2 + (q1 - q0); };
+    auto run_params = [&](int w, int q0, int q1, int* index) -> int {
+        const int k = run_index(w, q0, q1);
+        *index = k;
+        if (have[(size_t)k]) return STE_OK;
+        ste_ukf_batch_f64 b = sc->windows[w];
+        b.flags |= STE_FLAG_LANES_1;
+        b.step_begin = q0 * step;
+        b.step_end = std::min(b.Nmax, (q1 + 1) * step);
+        ste::KParams* kp = kps + k;
+        int rc = make_params(&b, false, false, kp);
+        if (rc) return rc;
+        rc = slice_params(&b, kp);
+        if (rc) return rc;
+        const int v = forward_variant(*kp);
+        if (variant >= 0 && v != variant)
+            return fail(STE_EINVAL, "scheduled forward pass: the windows must agree on H / R structure, robust flag and rts_work (one kernel runs them all)");
+        variant = v;
+        have[(size_t)k] = 1;
+        return STE_OK;
+    };
     // items: (window, tile) per (round, wave); the slice is the tile's number of earlier appearances.  Every tile must run
     // all its slices, in rounds that strictly increase.
     ste::SchedItem* items = (ste::SchedItem*)(hw + lay.items);
-    std::vector<int> next_slice(ntiles, 0), last_round(ntiles, -1);
+    std::vector<int> next_slice(ntiles, 0), last_round(ntiles, -1), last_wave(ntiles, -1);
+    std::vector<size_t> last_item(ntiles, 0);
     for (int r = 0; r < sc->nrounds; ++r)
         for (int v = 0; v < sc->nwaves; ++v) {
             const size_t i = (size_t)r * sc->nwaves + v;
@@ -2632,18 +2650,55 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
                 const int g = tile0[w] + tile, q = next_slice[g];
                 if (q >= nslices[w]) return fail(STE_EINVAL, "scheduled forward pass: a tile is scheduled for more slices than it has");
                 if (last_round[g] >= r) return fail(STE_EINVAL, "scheduled forward pass: two slices of one tile in the same round");
-                next_slice[g] = q + 1;
-                last_round[g] = r;
-                it.kp = kp0[w] + q;
+                it.kp = 0;  // (set below, once runs of slices are known)
                 it.tile = tile;
                 it.prog = g;
                 it.meta = q | (q + 1 == nslices[w] ? 0x100 : 0) | (w << 9);
+                if (q + 1 == nslices[w]) it.meta |= 0x40000000;  // the window's smoother reads what the last slice leaves
+                if (q > 0 && last_wave[g] != v) {                 // the tile changes waves: hand over through memory
+                    it.meta |= (int)0x80000000u;
+                    items[last_item[g]].meta |= 0x40000000;
+                }
+                next_slice[g] = q + 1;
+                last_round[g] = r;
+                last_wave[g] = v;
+                last_item[g] = i;
             }
             items[i] = it;
         }
     for (int w = 0; w < sc->nwindows; ++w)
         for (int g = tile0[w]; g < tile0[w + 1]; ++g)
             if (next_slice[g] != nslices[w]) return fail(STE_EINVAL, "scheduled forward pass: a tile is missing slices (every tile of every window must run all of them)");
+    // Runs: consecutive slices of a tile that follow one another on the SAME wave, nothing in between, become one item over
+    // the whole step range -- the step loop of a plain forward pass, with no state written out and read back at the slice
+    // boundaries inside it (same bits: that is what a slice boundary is).  The run publishes the count of its last slice;
+    // the rounds it swallows are idle entries of that wave's column.
+    for (int v = 0; v < sc->nwaves; ++v)
+        for (int r = 0; r < sc->nrounds;) {
+            ste::SchedItem& head = items[(size_t)r * sc->nwaves + v];
+            if (head.kp < 0) {
+                ++r;
+                continue;
+            }
+            const int w = (head.meta >> 9) & 0x1fffff, q0 = head.meta & 0xff;
+            int q1 = q0, r2 = r + 1;
+            while (r2 < sc->nrounds) {
+                ste::SchedItem& nx = items[(size_t)r2 * sc->nwaves + v];
+                if (nx.kp < 0 || nx.prog != head.prog || (nx.meta & 0xff) != q1 + 1 || nx.meta < 0) break;
+                // the run keeps its first slice's number, window and acquire flag; last-slice and release flags are its last slice's
+                head.meta = (head.meta & (int)(0xffu | (0x1fffffu << 9) | 0x80000000u)) | (nx.meta & 0x40000100);
+                ++q1;
+                nx.kp = -1;
+                ++r2;
+            }
+            int k = 0;
+            const int rc = run_params(w, q0, q1, &k);
+            if (rc) return rc;
+            head.kp = k;
+            head.tile |= (q1 + 1) << 24;  // the slice count the run publishes
+            r = r2;
+        }
+    if (ntiles >= (1u << 24)) return fail(STE_EINVAL, "scheduled forward pass: a window has too many tiles");
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return fail(STE_ENOGPU, "no HIP device");

@@ -888,7 +888,8 @@ class SmootherPipeline:
         Each batch's smoother goes on a smoother stream behind a one-wave gate that leaves when the batch's last tile has
         finished its last slice.  ``after_smoother(k, stream)``: optional, called for batch k with its smoother stream current,
         may return an event the batch's next use must wait for.  ``timing``: optional dict, gets ``forward`` = (start, end)
-        timing events around the scheduled launch and ``smoothers`` = list of (start, end) per batch.
+        timing events around the scheduled launch and ``smoothers`` = (start, end) around the smoother of every
+        ``timing["every"]``-th batch (default 4: every record is a packet on the stream's queue between two launches).
         ``final``: nothing follows this sequence: its last smoother gets the unrestricted stream.
         Returns the list of the batches' completion events."""
         torch = self.torch
@@ -989,12 +990,13 @@ class SmootherPipeline:
             binding.check(self.lib.ste_stream_wait_counter(counters.data_ptr() + 4 * i, ntiles[i], counters.data_ptr() + 4 * n,
                                                            float(timeout_s) * 4, C.c_void_p(bwd_stream.cuda_stream)),
                           "ste_stream_wait_counter")
-            if timing is not None:
+            timed = timing is not None and i % int(timing.get("every", 4)) == 0
+            if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 timing["smoothers"].append(ev)
                 ev[0].record(bwd_stream)
             db.backward(bwd_stream, mark=False)
-            if timing is not None:
+            if timed:
                 ev[1].record(bwd_stream)
             if after_smoother is not None:
                 with torch.cuda.stream(bwd_stream):
@@ -1231,10 +1233,12 @@ def fleet_windows(ntracks: int, chunk: int):
 # whole windows make up a chip-full of forward waves.  Measured on a resident 100 000 x 500 fleet
 # (profiles/r04_fleet_sweep.txt): 7 windows of 14 336 tracks 8.5 ms, 10 of 10 048 9.1 ms, 13 of 7 744 9.2 ms, one launch 9.5 ms.
 FLEET_CHUNK = 16_384
+# run_fleet's default: a resident fleet of at most this many windows runs its forward passes as one scheduled launch
+SCHEDULED_FLEET_MAX_WINDOWS = 24
 
 
 def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = True, outputs=None, pipeline=None,
-              slices: Optional[int] = None, sm_pos: bool = False, scheduled: bool = False):
+              slices: Optional[int] = None, sm_pos: bool = False, scheduled: Optional[bool] = None):
     """
     UKF + URTSS over a fleet of any size -- the batch dimension of the reference's example loop
     (examples/example_ukf_rts_smoother_batch.py:19-90, one ship at a time) at the rate the pipelined kernels sustain.
@@ -1254,7 +1258,10 @@ def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = T
     ``pipeline``: a ``SmootherPipeline`` to reuse (otherwise one is built for this call and closed at its end).
     ``scheduled``: a resident fleet's windows go through ``SmootherPipeline.submit_sequence`` -- all their forward passes as
         one launch of resident waves over (tile, time slice) items -- instead of one forward launch per window (same bits;
-        measured on a 100 000-track fleet: 8.3-8.4 against 8.5 ms).
+        measured on a 100 000-track fleet: 7.9-8.1 against 8.4-8.6 ms).  Default (None): yes for a
+        resident fleet of up to ``SCHEDULED_FLEET_MAX_WINDOWS`` windows on a lane-per-track pipeline -- a job that is mostly
+        fill and drain --, no for longer ones (a long stream of windows re-balances by itself) and for a ``HostBatch``
+        (its windows arrive one upload at a time).
     Results are those of ``run_batch`` on the same tracks with the lane-per-track mapping, bit for bit.
     """
     import torch
@@ -1303,6 +1310,8 @@ def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = T
                 attr, width = DeviceBatch._OUT[name]
                 host[name] = torch.empty((B, hb.Nmax + 1, width), dtype=torch.float64, pin_memory=True)
         keep = []
+        if scheduled is None:
+            scheduled = resident and 1 < len(wins) <= SCHEDULED_FLEET_MAX_WINDOWS and pipe.forward_lanes != 4
         if scheduled and resident and len(wins) > 1:
             ws = [db.window(lo, hi) for lo, hi in wins]
             dones = pipe.submit_sequence(ws, smooth=smooth)
