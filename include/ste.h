@@ -203,8 +203,10 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream);
  * SIMDs cost ceil(W T / S) pass times for W T / S pass times of work.  Here the unit is a (64-track tile, time slice) item,
  * the launch is `nwaves` resident waves (one per SIMD the stream may use), and `items` says which item every wave runs in
  * every round.  A tile's slices may run on different waves: each slice starts from the history row the one before it
- * left (the slices of ste_ukf_forward_f64: same bits as a whole pass), publishes the tile's slice count when its rows are
- * in memory, and the next slice waits for that count -- always an item of an EARLIER round.  The library checks the table
+ * left (the slices of ste_ukf_forward_f64: same bits as a whole pass); where a tile changes waves the finished slice
+ * publishes the tile's slice count once its rows are in memory (release, agent scope) and the next slice waits for that
+ * count (acquire) -- always an item of an EARLIER round; slices that follow one another on one wave are run as ONE item over
+ * the whole step range, with no hand-over at all (the library finds those runs in the table).  The library checks the table
  * (every tile of every window runs all its slices, in order, at most one per round) before anything is launched, and
  * every in-kernel wait is bounded: a launch that cannot progress sets *error and ends.
  *
