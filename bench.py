@@ -392,9 +392,12 @@ def _main(stack):
     ap.add_argument("--sequence", default="auto",
                     help="steps per SCHEDULED forward launch (SmootherPipeline.submit_sequence: the forward passes of that many "
                          "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
-                         "step, or 'auto' = 10 when --steps <= 40 (a short run is all fill and drain, which the schedule "
-                         "shortens: 0.75 against 0.80 ms per step at the driver's 20 steps), 0 for longer runs (in the steady "
-                         "state per-step launches re-balance by themselves and are 1-2 %% faster; DESIGN.md section 5)")
+                         "step, or 'auto'.  auto, one GPU and --steps <= 40 (a short run is all fill and drain, which a schedule "
+                         "shortens): two scheduled launches -- the first of as many steps as fill the chip once -- and one launch "
+                         "per step are both run untimed and the faster form is used (config.sequence_auto says which: 0.77-0.79 "
+                         "against 0.80 ms per step at the driver's 20 steps); longer runs and runs with an exchange: one launch "
+                         "per step (in the steady state per-step launches re-balance by themselves and are 1-2 %% faster; "
+                         "DESIGN.md section 5)")
     ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
     ap.add_argument("--fleet-tracks", type=int, default=100_000)
     ap.add_argument("--fleet-chunk", type=int, default=None, help="window size of the fleet entry (default: batch.FLEET_CHUNK)")
@@ -491,9 +494,23 @@ def _main(stack):
     if pipe is not None and args.lanes != 4 and (args.forward_lanes in (None, 1)):
         # auto: single-GPU runs only (with an exchange in the step the per-step launches are the measured configuration)
         seq = (10 if (args.steps <= 40 and dist is None) else 0) if args.sequence == "auto" else int(args.sequence)
+    # how a run of n steps is cut into scheduled launches.  auto: a first launch of as many steps as fill the chip's SIMDs once
+    # (7 at 10 000 tracks: its windows finish together after one pass and their smoothers start while the second launch, the
+    # rest, runs) -- measured at the driver's 20 steps: (7, 13) 14.8 ms, (8, 12) 15.0, (10, 10) 15.3, (20) 15.3, three launches
+    # 16.5+, one launch per step 16.1 (profiles/r05_scheduled_forward.txt)
+    first_fill = max(1, -(-1024 // max(1, -(-B // 64))))
+
+    def seq_plan(n):
+        if not seq or n <= 0:
+            return []
+        if args.sequence == "auto":
+            return [n] if n <= first_fill + 1 else [first_fill, n - first_fill]
+        return [min(seq, n - c0) for c0 in range(0, n, seq)]
+
     # per-step launches rotate through buffers_needed sets; a scheduled launch needs a set per step of the sequence, and two
     # sequences' worth so that the next sequence does not wait for the smoothers of the one before it
-    nsets = 1 if pipe is None else max(pipe.buffers_needed, min(2 * seq, max(args.steps, args.warmup)))
+    nsets = 1 if pipe is None else max(pipe.buffers_needed, (max(args.steps, args.warmup) if args.sequence == "auto" else
+                                                             min(2 * seq, max(args.steps, args.warmup))) if seq else 0)
     dbs = [db] + [mk() for _ in range(nsets - 1)]
     gathered = None
     if dist is not None and not args.no_gather:
@@ -539,8 +556,10 @@ def _main(stack):
             for k in range(nsteps):
                 one_step(k, None if events is None else events[k], final=(k == nsteps - 1))
             return
-        for c0 in range(0, nsteps, seq):
-            ks = list(range(c0, min(c0 + seq, nsteps)))
+        c0 = 0
+        for n in seq_plan(nsteps):
+            ks = list(range(c0, c0 + n))
+            c0 += n
             tm = {"every": EVENT_EVERY} if events is not None else None
             hook = None
             if gathered is not None:
@@ -548,8 +567,10 @@ def _main(stack):
                     if (ks[i] + 1) % args.gather_every == 0:
                         return gathered.launch_for_pipeline(dbs[ks[i] % len(dbs)].sm_pos)
                     return None
+            h0 = time.perf_counter()
             pipe.submit_sequence([dbs[k % len(dbs)] for k in ks], after_smoother=hook, timing=tm, final=(ks[-1] == nsteps - 1))
             if tm is not None:
+                tm["host_ms"] = (time.perf_counter() - h0) * 1e3  # the call queues work and returns: this is host time only
                 seq_timings.append((len(ks), tm))
 
     def drain():
@@ -591,6 +612,32 @@ def _main(stack):
         torch.cuda.synchronize(dev)
         run_steps(prepass)
         drain()
+    # auto: the two launch forms give the same bits, so the choice between them is made by the clock, untimed, on this box now
+    # (twice each, the better of the two): a scheduled launch has more in front of it than a per-step one (a table upload, the
+    # clearing of its counters), and on one of the boxes of round 5 that cost 10 ms per launch for tens of seconds at a time
+    auto_choice = None
+    if seq and args.sequence == "auto":
+        def wall(n):
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            run_steps(n)
+            drain()
+            return (time.perf_counter() - tw) * 1e3
+
+        keep = seq
+        try:
+            sched_ms = min(wall(args.steps) for _ in range(2))
+        except binding.SteError as exc:
+            print(f"[bench] scheduled forward launches disabled after an error in the untimed comparison: {exc}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize(dev)
+            sched_ms = float("inf")
+        seq = 0
+        step_ms = min(wall(args.steps) for _ in range(2))
+        seq = keep if sched_ms <= step_ms else 0
+        auto_choice = {"scheduled_launches_ms": sched_ms if np.isfinite(sched_ms) else None, "per_step_launches_ms": step_ms,
+                       "steps": args.steps, "chosen": "scheduled" if seq else "per_step",
+                       "note": "untimed, before the warm-up: wall time of --steps steps in either launch form (better of two runs "
+                               "each); the timed region uses the faster form -- both give the same histories bit for bit"}
     run_steps(args.warmup)
     drain()
     if dist is not None:
@@ -740,7 +787,7 @@ def _main(stack):
                 "substeps": SUBSTEPS,
                 "parallelism": f"track-sharded x{world}" + (f", {'RCCL' if os.environ.get('STE_BENCH_BACKEND', 'nccl') == 'nccl' else os.environ['STE_BENCH_BACKEND']} all-gather of smoothed lon/lat {'of every step' if args.gather_every == 1 else f'once per {args.gather_every} steps'}, overlapped with the following steps" if gathered is not None else ""),
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
-                             (f"the forward passes of every {seq} steps as ONE scheduled launch of {4 * (pipe.forward_cus - pipe.reserve_cus)} resident "
+                             (f"the forward passes of {' + '.join(str(n) for n in seq_plan(args.steps))} steps as ONE scheduled launch each of {4 * (pipe.forward_cus - pipe.reserve_cus)} resident "
                               "waves over (64-track tile, 64-step slice) items (SmootherPipeline.submit_sequence; bit-identical to "
                               f"per-step launches), each step's smoother behind a gate on one of {len(pipe.bwd_streams)} smoother streams, "
                               f"{len(dbs)} sets of histories in rotation") if seq else
@@ -752,12 +799,15 @@ def _main(stack):
                                 f"on {pipe.forward_cus} CUs beside {len(pipe.bwd_streams)} smoothers on the other {pipe.smoother_cus} CUs (CU-masked streams, ")
                              + f"{len(dbs)} sets of histories in rotation)"),
                 "lanes_per_track": args.lanes, "tuning": args.tuning, "untimed_prepass_steps": prepass,
-                "steps_per_scheduled_forward_launch": seq,
+                "steps_per_scheduled_forward_launch": seq_plan(args.steps) or 0,
+                "sequence_auto": auto_choice,
                 "gather_every": args.gather_every if gathered is not None else None,
             },
             "kernels_ms": {"ukf_forward": fwd_ms, "urtss_backward": bwd_ms,
                            "timed_launches": len(seq_timings) if seq else len([e for e in evs if e is not None]),
                            "steps_per_forward_launch": steps_per_launch,
+                           "scheduled_launches": ([{"steps": n, "forward_ms": tm["forward"][0].elapsed_time(tm["forward"][1]),
+                                                    "host_submit_ms": tm["host_ms"]} for n, tm in seq_timings] or None),
                            "note": ("HIP events around every scheduled forward launch (the forward passes of "
                                     f"{steps_per_launch:g} steps each) and around the smoother of every {EVENT_EVERY}th step" if seq else
                                     f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region")},

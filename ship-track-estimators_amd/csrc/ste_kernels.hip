@@ -1001,6 +1001,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+// Table upload of a scheduled launch as a kernel on the launch's own stream: copies `ncopy` 16-byte words from page-locked host
+// memory (read over the host link) into the device workspace and clears the `nzero` words behind them (the progress counters).
+// A copy-engine transfer in front of every scheduled launch is an engine shared with whatever else the node is doing: on one
+// box the 0.3 MB transfer took ~10 ms for tens of seconds at a time (profiles/r05_scheduled_forward.txt).
+__global__ __launch_bounds__(256) void sched_upload(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t ncopy, size_t nzero) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncopy + nzero; i += stride)
+        dst[i] = i < ncopy ? src[i] : make_uint4(0, 0, 0, 0);
+}
+
 // One wave that leaves when *counter >= need (or after the bound, raising *error): what a smoother's stream runs in front of
 // the smoother of a window whose forward pass is part of a scheduled launch on another stream.
 __global__ __launch_bounds__(64) void sched_gate(const int* counter, int need, int* error, unsigned long long timeout_ticks) {
@@ -2706,9 +2716,24 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
     if (sc->nwaves > 4 * ncu) return fail(STE_EINVAL, "scheduled forward pass: nwaves exceeds the device's SIMD count (4 per compute unit)");
     hipStream_t s = (hipStream_t)stream;
     char* dw = (char*)sc->dev_ws;
-    int rc = check_hip(hipMemcpyAsync(dw, hw, lay.progress, hipMemcpyHostToDevice, s), "scheduled forward pass: table upload");
-    if (rc) return rc;
-    rc = check_hip(hipMemsetAsync(dw + lay.progress, 0, lay.total - lay.progress, s), "scheduled forward pass: counters");
+    // page-locked host_ws: a kernel on `s` reads it in place (no copy engine between two launches); anything else: a staged copy
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const bool locked = hipPointerGetAttributes(&attr, hw) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer &&
+                        ((uintptr_t)attr.devicePointer & 15) == 0 && ((uintptr_t)dw & 15) == 0;
+    int rc = STE_OK;
+    if (locked) {
+        const size_t nwords = lay.total / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>(256, (nwords + 255) / 256);
+        hipLaunchKernelGGL(ste::sched_upload, dim3(blocks), dim3(256), 0, s, (uint4*)dw, (const uint4*)attr.devicePointer,
+                           lay.progress / 16, (lay.total - lay.progress) / 16);
+        rc = check_hip(hipGetLastError(), "scheduled forward pass: table upload");
+    } else {
+        (void)hipGetLastError();  // (the attribute query of pageable memory reports an error: not this call's)
+        rc = check_hip(hipMemcpyAsync(dw, hw, lay.progress, hipMemcpyHostToDevice, s), "scheduled forward pass: table upload");
+        if (rc) return rc;
+        rc = check_hip(hipMemsetAsync(dw + lay.progress, 0, lay.total - lay.progress, s), "scheduled forward pass: counters");
+    }
     if (rc) return rc;
     ste::SchedParams sp;
     sp.kps = (const ste::KParams*)(dw + lay.kps);

@@ -755,6 +755,7 @@ class SmootherPipeline:
         self._batches = []  # weak references to the DeviceBatches that carry one of this pipeline's events
         self._schedules = {}  # item tables of scheduled forward launches, by shape (submit_sequence)
         self._sched_live = []  # workspaces / counters of scheduled launches not yet synchronised
+        self._sched_free = []  # ... and of retired ones, kept for the next launch: no allocator call on the launch path
         self.buffers_needed = forward_streams + smoother_streams + 1
         # time slices per forward pass (DeviceBatch.forward): the waves of the passes in flight re-balance over the SIMDs at
         # every slice boundary instead of once per pass (3.6-4.5 ms at 500 steps) -- what a short sequence of batches, or
@@ -948,10 +949,22 @@ class SmootherPipeline:
                 self._schedules.clear()
             self._schedules[skey] = items
         nbytes = int(self.lib.ste_ukf_forward_sched_workspace(n, max(nslices), sum(ntiles), items.shape[0], nwaves))
+        # workspace and counters come from the launches retired before (synchronize / the pruning above): an allocation here
+        # -- pinned host memory above all -- is a driver call of unbounded length in the middle of a sequence of launches
+        host_ws = dev_ws = counters_all = None
+        for j, (cap, h, d, c) in enumerate(self._sched_free):
+            if cap >= nbytes and c.numel() >= n + 1:
+                host_ws, dev_ws, counters_all = h, d, c
+                del self._sched_free[j]
+                break
         with torch.cuda.stream(fwd_stream):
-            host_ws = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
-            dev_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            counters = torch.zeros(n + 1, dtype=torch.int32, device=self.device)  # [0 .. n) window_done, [n] error
+            if host_ws is None:
+                cap = max(1 << 20, 1 << (nbytes - 1).bit_length())
+                host_ws = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                dev_ws = torch.empty(cap, dtype=torch.uint8, device=self.device)
+                counters_all = torch.empty(max(64, n + 1), dtype=torch.int32, device=self.device)
+            counters = counters_all[:n + 1]  # [0 .. n) window_done, [n] error
+            counters.zero_()
             zeroed = torch.cuda.Event()
             zeroed.record(fwd_stream)
         sc = binding.SteFwdSchedF64()
@@ -972,7 +985,7 @@ class SmootherPipeline:
         # the launch's tables and counters stay alive until the pipeline is synchronised, or every gate and smoother that
         # looks at them has finished (their error word is read then)
         events = []
-        self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events))
+        self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events, counters_all))
         waited = set()
         for i, db in enumerate(dbs):
             if getattr(db, "_pipeline_done", None) is None:
@@ -1011,6 +1024,7 @@ class SmootherPipeline:
         """After a synchronisation: the error words of the scheduled launches issued since the last one."""
         live, self._sched_live = self._sched_live, []
         bad = [int(e[2][-1].item()) for e in live]
+        self._sched_free = ([(e[0].numel(), e[0], e[1], e[7]) for e in live] + self._sched_free)[:16]
         if any(bad):
             raise binding.SteError("a scheduled forward launch could not progress (error word %s: 1 = a forward wave, 2 = a smoother "
                                    "gate waited longer than its bound); results of that sequence are incomplete" % bad)
@@ -1040,6 +1054,7 @@ class SmootherPipeline:
                     db._pipeline_done = None
             self._batches = []
             self._sched_live = []
+            self._sched_free = []
             self.fwd_streams, self.bwd_streams, self._tail_stream = [], [], None
             raw, self._raw = self._raw, []
             for h in raw:

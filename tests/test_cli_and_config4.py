@@ -393,7 +393,7 @@ def test_bench_two_rank_control_flow():
     res = subprocess.run(cmd3, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     out3 = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
-    assert out3["config"]["steps_per_scheduled_forward_launch"] == 2 and out3["status_flagged_tracks"] == 0 and out3["value"] > 0
+    assert out3["config"]["steps_per_scheduled_forward_launch"] == [2] and out3["status_flagged_tracks"] == 0 and out3["value"] > 0
     assert out["config"]["steps_per_scheduled_forward_launch"] == 0  # auto: per-step launches when ranks exchange
 
 
@@ -461,8 +461,17 @@ def test_bench_line_carries_the_contract():
     assert abs(r["achieved"] - 512 * out["value"] / 1e9) < 1e-6 * r["achieved"] and r["algorithmic_bytes_per_track_step"] == 512
     pl = r["per_launch"]  # one launch of the dominant kernel over its own HIP-event duration
     assert pl["kernel"] == "ukf_forward" and pl["launch_ms"] > 0 and pl["launches_in_flight"] >= 1
-    # (30 steps: bench.py --sequence auto runs the forward passes as scheduled launches of 10 steps each)
-    assert pl["steps_per_launch"] == 10 and out["config"]["steps_per_scheduled_forward_launch"] == 10
+    # bench.py --sequence auto: the clock chooses, untimed, between one launch per step and scheduled launches (30 steps of 10
+    # tiles do not fill the chip: ONE scheduled launch), and the line says which it took and what either cost
+    auto = out["config"]["sequence_auto"]
+    assert auto["steps"] == 30 and auto["per_step_launches_ms"] > 0 and auto["scheduled_launches_ms"] > 0
+    if auto["chosen"] == "scheduled":
+        assert auto["scheduled_launches_ms"] <= auto["per_step_launches_ms"]
+        assert pl["steps_per_launch"] == 30 and out["config"]["steps_per_scheduled_forward_launch"] == [30]
+        assert [d["steps"] for d in out["kernels_ms"]["scheduled_launches"]] == [30]
+    else:
+        assert auto["chosen"] == "per_step" and auto["scheduled_launches_ms"] > auto["per_step_launches_ms"]
+        assert pl["steps_per_launch"] == 1 and out["config"]["steps_per_scheduled_forward_launch"] == 0
     assert abs(pl["achieved"] - 192 * 640 * 500 * pl["steps_per_launch"] / (pl["launch_ms"] * 1e-3) / 1e9) < 1e-6 * pl["achieved"]
     fl = out["extra"]["fleet_100k"]  # the product entry point for a fleet, on a small one here
     assert fl["bit_identical_to_one_launch"] is True and fl["track_steps"] == 1500 * 500 and fl["value"] > 0
