@@ -214,8 +214,9 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream);
  * stream holds that stream until the window's forward pass is complete (its smoother goes behind it).
  *
  * All windows must take the same kernel (same H / R structure, robust flag, rts_work present or not); lane-per-track
- * mapping only.  host_ws must be page-locked for the upload to be asynchronous and stay untouched until the launch has
- * started; dev_ws is filled by the call's own stream operations.  window_done and error must be ZERO when the launch starts:
+ * mapping only.  host_ws should be page-locked (hipHostMalloc / hipHostRegister): a kernel on `stream` then reads the table
+ * from it in place, and nothing but kernels sits between two launches; pageable memory goes through a staged copy.  Either
+ * way it must stay untouched until the launch has started; dev_ws is filled by the call's own stream operations.  window_done and error must be ZERO when the launch starts:
  * the caller clears them on `stream` before the call (and orders every stream that will wait on a counter behind that
  * clearing), the call does not. */
 typedef struct ste_fwd_sched_f64 {
@@ -225,7 +226,7 @@ typedef struct ste_fwd_sched_f64 {
     int32_t nwaves;                   /* waves of the launch; all must be resident at once: <= SIMDs the stream may use */
     int32_t nrounds;
     const int32_t* items;             /* HOST [nrounds][nwaves][2]: (window, tile of that window), window < 0 = idle */
-    void* host_ws;                    /* HOST scratch, ws_bytes (ste_ukf_forward_sched_workspace) */
+    void* host_ws;                    /* HOST scratch (page-locked if possible), ws_bytes (ste_ukf_forward_sched_workspace) */
     void* dev_ws;                     /* DEVICE scratch, ws_bytes */
     size_t ws_bytes;
     int32_t* window_done;             /* DEVICE [nwindows], zero at launch */

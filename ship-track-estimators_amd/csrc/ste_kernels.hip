@@ -10,8 +10,9 @@
 //                                        flag); with rts_work they also leave the smoother's cross-covariance D and,
 //                                        where it does not follow from the history, its x_b and P_b
 //   ukf_forward_sched + sched_gate       the forward passes of MANY batches / fleet windows as one launch of resident waves
-//                                        working through a host-made schedule of (64-track tile, time slice) items -- the
-//                                        body is ukf_forward_l1's --, and the one-wave gate a smoother's stream waits behind
+//     + sched_upload                     working through a host-made schedule of (64-track tile, time slice) items -- the
+//                                        body is ukf_forward_l1's --, the one-wave gate a smoother's stream waits behind,
+//                                        and the upload of the schedule's table from page-locked memory
 //   urtss_recur_l1                       smoother from those rows, one lane per track: gain K = D pinv(P_b), recurrence
 //                                        (batches that fill the chip)
 //   urtss_gains_all + urtss_recur_lean   the same smoother in two kernels for batches of <= 4 096 tracks: every gain of
