@@ -711,7 +711,12 @@ __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work,
     for (int c = 0; c < T; ++c) {
         const double piv = readlane_f64(a[c], c);
         good = good && (piv > 0.0);
-        const double rd = 1.0 / sqrt(piv > 0.0 ? piv : 1.0);
+        // 1 / sqrt(piv): v_rsq_f64 and one third-order correction (~2^-70 before rounding) instead of the library's sqrt and
+        // a division, ~60 dependent instructions per column on the one wave everything else waits for
+        const double pv = piv > 0.0 ? piv : 1.0;
+        const double y0 = __builtin_amdgcn_rsq(pv);
+        const double e0 = fma(-(pv * y0), y0, 1.0);
+        const double rd = fma(y0 * e0, fma(0.375, e0, 0.5), y0);
         const double l = a[c] * rd;  // lane c: sqrt(piv); lanes below: the column of L; lanes above: unused
         a[c] = l;
         col[lane] = l;
@@ -742,7 +747,8 @@ __device__ __noinline__ void chol_trinv_wave(double* S, double* X, double* work,
             acc1 = fma(-l2[1], x[k + 1], acc1);
         }
         if (r & 1) acc0 = fma(-work[r * LDB + r - 1], x[r - 1], acc0);
-        x[r] = (acc0 + acc1) / work[r * LDB + r];
+        x[r] = (acc0 + acc1) / work[r * LDB + r];  // (times 1 / L[r][r] kept from the factor loop: 380 instructions fewer and
+                                                   //  1 500 register moves more -- the rows' loads then crowd the registers)
     }
 #pragma unroll
     for (int c = 0; c < T; ++c) X[c * LD + lane] = x[c];  // x[c] of lane `lane` = X[row c][column lane]

@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ste.h"
@@ -1030,13 +1031,15 @@ __device__ __forceinline__ int tri_index(int r, int c) { return r * 4 - (r * (r 
 // zero and x_b cancels in the difference), and P_b, which is centred on x_k instead of on the predicted mean, follows
 // from the predicted covariance by P_b = P^- + e b^T + b e^T + b b^T with b = x^- - x_k and e = (weighted mean) - x^-
 // (= minus the injected predict noise; zero in noise-free runs), because the weights sum to one.
+template <class KT, class KG>
 __device__ __forceinline__ int quad_predict(const Mats& p, const QuadCtx& cx, double (&x)[4], double (&Px)[4],
                                             QuadBasis& basis, double dt, double sr, double cr, const double* noise,
                                             const double* noise_rts, double* work, size_t nrow, size_t B, size_t t,
-                                            bool full_row, bool noise_mode, bool& flagged, double* first_bad) {
+                                            bool full_row, bool noise_mode, bool& flagged, double* first_bad,
+                                            const KT& tk, const KG& gk) {
     double Tn[4], s0[4], sp[4], sm[4], m[4], xp[4];
     int st = quad_sym_sqrt(Px, p.fan_scale, cx, basis, Tn);
-    quad_propagate(x, Tn, dt, sr, cr, s0, sp, sm);
+    quad_propagate<KT, KG>(x, Tn, dt, sr, cr, s0, sp, sm, tk, gk);
     STE_UNROLL
     for (int c = 0; c < 4; ++c) m[c] = fma(p.w0, s0[c], p.wi * quad_sum(sp[c] + sm[c]));
     STE_UNROLL
@@ -1335,6 +1338,14 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
     if (cont && ns <= 0) return;
     QuadCtx cx;
     quad_ctx_init(p.m, q, cx);
+    // the sin / cos and arctangent polynomial coefficients in VGPRs for the whole kernel: a wave that has its SIMD to itself
+    // pays an issue slot for every s_mov_b32 that brings half a literal into a register (92 of them in the step's main block,
+    // 46 with these 23 coefficients resident).  The closed-form update (kSel) leaves the 46 registers free; the general one
+    // (246-256 registers already) keeps the literals.
+    typename std::conditional<kSel, TrigReg, TrigLit>::type tk;
+    typename std::conditional<kSel, GeoReg, GeoLit>::type gk;
+    trig_reg_init(tk);
+    geo_reg_init(gk);
 
     double x[4], Px[4];
     STE_UNROLL
@@ -1379,7 +1390,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
         QuadBasis cold;
         cold.valid = false;
         st |= quad_predict(p.m, cx, xc, Pc, cold, p.dt[t], p.sog_rate[t], p.cog_rate[t], nullptr, p.noise_rts,
-                           p.rts_work, 0, B, t, true, noise_mode, flagged, first_bad);
+                           p.rts_work, 0, B, t, true, noise_mode, flagged, first_bad, tk, gk);
     }
     if (initial_update) {
         double z0[4];
@@ -1418,7 +1429,7 @@ __global__ __launch_bounds__(64, 2) void ukf_forward_q4(const KParams p) {
             if ((k & (kColdEvery - 1)) == 0) basis.valid = false;
             double* work = (kGains && !(k == 0 && initial_update)) ? p.rts_work : nullptr;
             st |= quad_predict(p.m, cx, x, Px, basis, dt, sr, cr, p.noise_pred, p.noise_rts, work, (size_t)k, B, t,
-                               (ui >= 0 && ui_ok) || noise_mode, noise_mode, flagged, first_bad);
+                               (ui >= 0 && ui_ok) || noise_mode, noise_mode, flagged, first_bad, tk, gk);
             if (ui >= 0 && ui_ok)
                 st |= kSel ? quad_update_sel2<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t)
                            : quad_update<kRobust>(p.m, cx, x, Px, zk, p.noise_upd, (size_t)k + 1, B, t);

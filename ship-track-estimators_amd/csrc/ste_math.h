@@ -233,6 +233,7 @@ __device__ __forceinline__ double in_vgpr(double v) {  // opaque to the optimise
     asm volatile("" : "+v"(v));
     return v;
 }
+__device__ __forceinline__ void trig_reg_init(TrigLit&) {}
 __device__ __forceinline__ void trig_reg_init(TrigReg& k) {
     k.s1 = in_vgpr(TrigLit::s1);
     k.s2 = in_vgpr(TrigLit::s2);
@@ -316,8 +317,40 @@ __device__ __forceinline__ void sincos_delta_n(const double (&d)[N], double (&s)
     sincos_kernel_n<N, K>(d, s, c, k);
 }
 
-template <int N>
-__device__ __forceinline__ void atan_small_n(const double (&q)[N], double (&out)[N]) {
+// The same choice for the arctangent and arcsine polynomials of geodetic_finish_n (GeoLit: literals; GeoReg: VGPRs for the
+// whole kernel -- the quad kernels, whose lone wave pays an issue slot for every s_mov_b32 and has registers to spare).
+struct GeoLit {
+    static constexpr double t0 = 1.62858201153657823623e-02, t1 = 4.97687799461593236017e-02, t2 = 6.66107313738753120669e-02,
+                            t3 = 9.09088713343650656196e-02, t4 = 1.42857142725034663711e-01, t5 = 3.33333333333329318027e-01,
+                            u0 = -3.65315727442169155270e-02, u1 = -5.83357013379057348645e-02, u2 = -7.69187620504482999495e-02,
+                            u3 = -1.11111104054623557880e-01, u4 = -1.99999999998764832476e-01;
+    static constexpr double p0 = 3.47933107596021167570e-05, p1 = 7.91534994289814532176e-04, p2 = -4.00555345006794114027e-02,
+                            p3 = 2.01212532134862925881e-01, p4 = -3.25565818622400915405e-01, p5 = 1.66666666666666657415e-01,
+                            q0 = 7.70381505559019352791e-02, q1 = -6.88283971605453293030e-01, q2 = 2.02094576023350569471e+00,
+                            q3 = -2.40339491173441421878e+00;
+};
+struct GeoReg {
+    double t0, t1, t2, t3, t4, t5, u0, u1, u2, u3, u4;
+    static constexpr double p0 = GeoLit::p0, p1 = GeoLit::p1, p2 = GeoLit::p2, p3 = GeoLit::p3, p4 = GeoLit::p4, p5 = GeoLit::p5,
+                            q0 = GeoLit::q0, q1 = GeoLit::q1, q2 = GeoLit::q2, q3 = GeoLit::q3;
+};
+__device__ __forceinline__ void geo_reg_init(GeoLit&) {}
+__device__ __forceinline__ void geo_reg_init(GeoReg& k) {
+    k.t0 = in_vgpr(GeoLit::t0);
+    k.t1 = in_vgpr(GeoLit::t1);
+    k.t2 = in_vgpr(GeoLit::t2);
+    k.t3 = in_vgpr(GeoLit::t3);
+    k.t4 = in_vgpr(GeoLit::t4);
+    k.t5 = in_vgpr(GeoLit::t5);
+    k.u0 = in_vgpr(GeoLit::u0);
+    k.u1 = in_vgpr(GeoLit::u1);
+    k.u2 = in_vgpr(GeoLit::u2);
+    k.u3 = in_vgpr(GeoLit::u3);
+    k.u4 = in_vgpr(GeoLit::u4);
+}
+
+template <int N, class K = GeoLit>
+__device__ __forceinline__ void atan_small_n(const double (&q)[N], double (&out)[N], const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double z[N], w[N], s1[N], s2[N];
     STE_UNROLL
@@ -326,51 +359,51 @@ __device__ __forceinline__ void atan_small_n(const double (&q)[N], double (&out)
         w[i] = z[i] * z[i];
     }
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], k.t0, k.t1);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 6.66107313738753120669e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], k.t2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 9.09088713343650656196e-02);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], k.t3);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 1.42857142725034663711e-01);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], k.t4);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], 3.33333333333329318027e-01);
+    for (int i = 0; i < N; ++i) s1[i] = fma(w[i], s1[i], k.t5);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], k.u0, k.u1);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -7.69187620504482999495e-02);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], k.u2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -1.11111104054623557880e-01);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], k.u3);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], -1.99999999998764832476e-01);
+    for (int i = 0; i < N; ++i) s2[i] = fma(w[i], s2[i], k.u4);
     STE_UNROLL
     for (int i = 0; i < N; ++i) out[i] = fma(-q[i], fma(z[i], s1[i], w[i] * s2[i]), q[i]);
 }
 
-template <int N>
-__device__ __forceinline__ void asin_small_n(const double (&x)[N], double (&out)[N]) {
+template <int N, class K = GeoLit>
+__device__ __forceinline__ void asin_small_n(const double (&x)[N], double (&out)[N], const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double t[N], pn[N], qd[N];
     STE_UNROLL
     for (int i = 0; i < N; ++i) t[i] = x[i] * x[i];
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], k.p0, k.p1);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], -4.00555345006794114027e-02);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], k.p2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], 2.01212532134862925881e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], k.p3);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], -3.25565818622400915405e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], k.p4);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], 1.66666666666666657415e-01);
+    for (int i = 0; i < N; ++i) pn[i] = fma(t[i], pn[i], k.p5);
     STE_UNROLL
     for (int i = 0; i < N; ++i) pn[i] *= t[i];
     STE_UNROLL
-    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], k.q0, k.q1);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], 2.02094576023350569471e+00);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], k.q2);
     STE_UNROLL
-    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], -2.40339491173441421878e+00);
+    for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], k.q3);
     STE_UNROLL
     for (int i = 0; i < N; ++i) qd[i] = fma(t[i], qd[i], 1.0);
     STE_UNROLL
@@ -378,11 +411,11 @@ __device__ __forceinline__ void asin_small_n(const double (&x)[N], double (&out)
 }
 
 // geodetic_finish for N points; ok &= the fast atan2 / asin paths apply to all of them
-template <int N>
+template <int N, class K = GeoLit>
 __device__ __forceinline__ void geodetic_finish_n(const double (&lon_r)[N], const double (&lat_r)[N], const double (&sp)[N],
                                                   const double (&cp)[N], const double (&sa)[N], const double (&ca)[N],
                                                   const double (&sd)[N], const double (&cd)[N], double (&lon_out)[N],
-                                                  double (&lat_out)[N], bool& ok) {
+                                                  double (&lat_out)[N], bool& ok, const K& k = K()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     double a[N], b[N], sl[N], h2[N], xs[N], qa[N], at[N], as[N];
     STE_UNROLL
@@ -396,14 +429,14 @@ __device__ __forceinline__ void geodetic_finish_n(const double (&lon_r)[N], cons
     }
     STE_UNROLL
     for (int i = 0; i < N; ++i) qa[i] = div_pos(a[i], b[i]);
-    atan_small_n<N>(qa, at);
+    atan_small_n<N, K>(qa, at, k);
     STE_UNROLL
     for (int i = 0; i < N; ++i) {
         const double cl = h2[i] * rsqrt_fast(h2[i]);
         xs[i] = fma(sl[i], cp[i], -(cl * sp[i]));
         ok = ok && (fabs(xs[i]) <= 0.5) && (h2[i] > 1e-300) && (cd[i] > 0.0);  // cd > 0: see geodetic_finish
     }
-    asin_small_n<N>(xs, as);
+    asin_small_n<N, K>(xs, as, k);
     STE_UNROLL
     for (int i = 0; i < N; ++i) {
         lon_out[i] = (lon_r[i] + at[i]) * kRad2Deg;

@@ -416,8 +416,11 @@ __device__ __forceinline__ void quad_propagate_branching(const double (&x)[4], c
 
 // The same three points with the three-at-a-time, branch-free helpers of ste_math.h; the rare wave in which some lane
 // leaves their validity range (a pole, a giant step, non-finite data) redoes the step with the branching version.
+// (KT, KG: where the polynomial coefficients come from -- literals, or registers set up once per kernel: ste_math.h)
+template <class KT = TrigLit, class KG = GeoLit>
 __device__ __forceinline__ void quad_propagate(const double (&x)[4], const double (&Tn)[4], double dt, double sr,
-                                               double cr, double (&s0)[4], double (&sp)[4], double (&sm)[4]) {
+                                               double cr, double (&s0)[4], double (&sp)[4], double (&sm)[4],
+                                               const KT& tk = KT(), const KG& gk = KG()) {
 #pragma clang fp contract(off)  // explicit fma() only: the same bits in every kernel this is inlined into
     const double dt_r = div_earth_radius(dt);
     const double du = sr * dt, da = cr * dt;
@@ -425,10 +428,10 @@ __device__ __forceinline__ void quad_propagate(const double (&x)[4], const doubl
     bool ok = true;
     const double a0[3] = {lat0, alpha0, delta0};
     double s_0[3], c_0[3];
-    sincos_fast_n<3>(a0, s_0, c_0, ok);
+    sincos_fast_n<3, KT>(a0, s_0, c_0, ok, tk);
     const double dl[3] = {Tn[1] * kDeg2Rad, Tn[3] * kDeg2Rad, Tn[2] * dt_r};
     double s_d[3], c_d[3];
-    sincos_delta_n<3>(dl, s_d, c_d, ok);
+    sincos_delta_n<3, KT>(dl, s_d, c_d, ok, tk);
     const double sp0 = s_0[0], cp0 = c_0[0], sa0 = s_0[1], ca0 = c_0[1], sd0 = s_0[2], cd0 = c_0[2];
     // angle addition for the +/- pair: sin(a +- d) = sin a cos d +- cos a sin d, cos(a +- d) = cos a cos d -+ sin a sin d
     const double p2 = cp0 * s_d[0], p4 = sp0 * s_d[0], a2 = ca0 * s_d[1], a4 = sa0 * s_d[1], d2 = cd0 * s_d[2],
@@ -448,7 +451,7 @@ __device__ __forceinline__ void quad_propagate(const double (&x)[4], const doubl
     const double vsd[3] = {sd0, fma(sd0, c_d[2], d2), fma(sd0, c_d[2], -d2)};
     const double vcd[3] = {cd0, fma(cd0, c_d[2], -d4), fma(cd0, c_d[2], d4)};
     double lon_o[3], lat_o[3];
-    geodetic_finish_n<3>(lon_r, lat_r, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok);
+    geodetic_finish_n<3, KG>(lon_r, lat_r, vsp, vcp, vsa, vca, vsd, vcd, lon_o, lat_o, ok, gk);
     // a lane whose inputs are already non-finite fails every range test but ends in NaN on either path: it must not send
     // its wave through the slow one (see lane_predict)
     const double fin = (dt + sr + cr + x[0] + x[1] + x[2] + x[3] + Tn[0] + Tn[1] + Tn[2] + Tn[3]) * 0.0;
