@@ -756,6 +756,7 @@ class SmootherPipeline:
         self._schedules = {}  # item tables of scheduled forward launches, by shape (submit_sequence)
         self._sched_live = []  # workspaces / counters of scheduled launches not yet synchronised
         self._sched_free = []  # ... and of retired ones, kept for the next launch: no allocator call on the launch path
+        self._sched_pinned = True  # page-locked host workspaces: the table is uploaded by a kernel (False: staged copy; tests)
         self.buffers_needed = forward_streams + smoother_streams + 1
         # time slices per forward pass (DeviceBatch.forward): the waves of the passes in flight re-balance over the SIMDs at
         # every slice boundary instead of once per pass (3.6-4.5 ms at 500 steps) -- what a short sequence of batches, or
@@ -960,7 +961,7 @@ class SmootherPipeline:
         with torch.cuda.stream(fwd_stream):
             if host_ws is None:
                 cap = max(1 << 20, 1 << (nbytes - 1).bit_length())
-                host_ws = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+                host_ws = torch.empty(cap, dtype=torch.uint8, pin_memory=self._sched_pinned)
                 dev_ws = torch.empty(cap, dtype=torch.uint8, device=self.device)
                 counters_all = torch.empty(max(64, n + 1), dtype=torch.int32, device=self.device)
             counters = counters_all[:n + 1]  # [0 .. n) window_done, [n] error

@@ -178,6 +178,26 @@ def test_sequence_of_batches_is_the_per_batch_launches_bit_for_bit():
             assert _same(r, d)
         with pytest.raises(ValueError, match="histories of its own"):
             pipe.submit_sequence([seqs[0], seqs[0]])
+        # workspaces of retired launches are kept and reused: the launches above were never more than two at a time
+        assert 1 <= len(pipe._sched_free) <= 2 and not pipe._sched_live
+        kept = {h.data_ptr() for _cap, h, _d, _c in pipe._sched_free}
+        for d in seqs:
+            _clear(d)
+        pipe.submit_sequence(seqs)
+        assert pipe._sched_live[-1][0].data_ptr() in kept
+        pipe.synchronize()
+        for r, d in zip(refs, seqs):
+            assert _same(r, d)
+        # a pageable host workspace (what a caller of the C ABI without page-locked memory hands over) takes the staged copy
+        # instead of the upload kernel: same table, same bits
+        pipe._sched_free, pipe._sched_pinned = [], False
+        for d in seqs:
+            _clear(d)
+        pipe.submit_sequence(seqs)
+        assert not pipe._sched_live[-1][0].is_pinned()
+        pipe.synchronize()
+        for r, d in zip(refs, seqs):
+            assert _same(r, d)
 
 
 @pytest.mark.gpu

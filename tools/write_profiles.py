@@ -68,7 +68,8 @@ with open(f"profiles/{RN}_counters_per_track_step.csv", "w") as f:
             short, k, c["FETCH_SIZE"] * 2048 / TS, c["WRITE_SIZE"] * 1024 / TS, flops, c["SQ_INSTS_VALU"] / w / 500,
             c["SQ_INSTS_SALU"] / w / 500, sum(f64) / w / 500, w, sum(dur[k]) / len(dur[k])))
 for src, dst in (("stats/**/*kernel_stats.csv", f"profiles/{RN}_pipelined_kernel_stats.csv"), ("bench_k100.json", f"profiles/{RN}_bench_default.json"),
-                 ("bench_driver_form.json", f"profiles/{RN}_bench_driver_form.json")):
+                 ("bench_driver_form.json", f"profiles/{RN}_bench_driver_form.json"),
+                 ("stats_driver_form/**/*kernel_stats.csv", f"profiles/{RN}_driver_form_kernel_stats.csv")):
     m = glob.glob(os.path.join(root, src), recursive=True)
     if m:
         shutil.copy(m[0], dst)
