@@ -216,9 +216,16 @@ int ste_ukf_forward_f64(const ste_ukf_batch_f64* b, void* stream);
  * All windows must take the same kernel (same H / R structure, robust flag, rts_work present or not); lane-per-track
  * mapping only.  host_ws should be page-locked (hipHostMalloc / hipHostRegister): a kernel on `stream` then reads the table
  * from it in place, and nothing but kernels sits between two launches; pageable memory goes through a staged copy.  Either
- * way it must stay untouched until the launch has started; dev_ws is filled by the call's own stream operations.  window_done and error must be ZERO when the launch starts:
- * the caller clears them on `stream` before the call (and orders every stream that will wait on a counter behind that
- * clearing), the call does not. */
+ * way it must stay untouched until the launch has started; dev_ws is filled by the call's own stream operations.  window_done,
+ * error and started must be ZERO when the launch starts: the caller clears them on `stream` before the call (and orders
+ * every stream that will wait on a counter behind that clearing), the call does not.
+ *
+ * Residency.  A wave may wait for any other wave of its launch, so all `nwaves` must be on the chip together.  One such
+ * launch at a time gets there by itself; two that are dispatched together can each take part of the SIMDs and wait for
+ * the rest until their bounds expire.  `started` (optional) counts the waves of this launch that have begun: put
+ * ste_stream_wait_counter(started of the launch before, its nwaves, ...) on the stream in front of the next call and the
+ * next launch is not dispatched before the one before it is resident (SmootherPipeline does, across pipelines of a process;
+ * launches of different processes on one device are the caller's to keep apart). */
 typedef struct ste_fwd_sched_f64 {
     int32_t nwindows;
     const ste_ukf_batch_f64* windows; /* HOST [nwindows]; step_begin = step_end = 0 */
@@ -232,6 +239,7 @@ typedef struct ste_fwd_sched_f64 {
     int32_t* window_done;             /* DEVICE [nwindows], zero at launch */
     int32_t* error;                   /* DEVICE [1], zero at launch: 1 = a forward wait timed out, 2 = a gate (wait_counter) did */
     double timeout_s;                 /* bound of one in-kernel wait; 0 = 2 s */
+    int32_t* started;                 /* DEVICE [1] or NULL, zero at launch: waves of this launch that have begun */
 } ste_fwd_sched_f64;
 
 /* bytes of host_ws / dev_ws for a schedule of that shape (max_slices = largest ceil(Nmax / slice_steps) over the windows) */

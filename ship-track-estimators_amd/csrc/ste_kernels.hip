@@ -953,6 +953,7 @@ struct SchedParams {
     int* window_done;  // [nwindows] tiles finished, zeroed before the launch
     int* error;        // one word, zeroed before the launch: 1 = a wait timed out (the schedule could not progress)
     unsigned long long timeout_ticks;  // bound of a single wait, in s_memrealtime ticks (100 MHz)
+    int* started;      // optional, zeroed before the launch: waves that have begun (== nwaves: the launch is resident)
 };
 
 // wave-uniform: spin (sleeping) until *flag >= need or the bound is reached
@@ -972,6 +973,7 @@ template <bool kGains, bool kFastUpd, bool kRobust>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void ukf_forward_sched(const SchedParams sp) {
     typedef const KParams __attribute__((address_space(4))) ConstKParams;  // the table is constant for the launch: scalar loads,
                                                                            // re-materialised where they are used like kernel arguments
+    if (sp.started && threadIdx.x == 0) __hip_atomic_fetch_add(sp.started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int r = 0; r < sp.nrounds; ++r) {
         const SchedItem* ip = sp.items + ((size_t)r * sp.nwaves + blockIdx.x);
         const int kp = __builtin_amdgcn_readfirstlane(ip->kp);
@@ -2756,6 +2758,7 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
     sp.window_done = sc->window_done;
     sp.error = sc->error;
     sp.timeout_ticks = (unsigned long long)((sc->timeout_s > 0 ? sc->timeout_s : 2.0) * 1e8);
+    sp.started = sc->started;
     const dim3 grid((unsigned)sc->nwaves), block(64);
     switch (variant) {
 #define STE_SCHED(n, g, f, r) \

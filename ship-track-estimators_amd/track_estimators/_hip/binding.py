@@ -95,6 +95,7 @@ class SteFwdSchedF64(C.Structure):
         ("window_done", _dp),
         ("error", _dp),
         ("timeout_s", C.c_double),
+        ("started", _dp),
     ]
 
 

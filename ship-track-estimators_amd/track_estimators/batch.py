@@ -662,6 +662,11 @@ def forward_schedule(ntiles: Sequence[int], nslices: Sequence[int], nwaves: int,
     return items[:r]
 
 
+# the most recent scheduled forward launch per device, of any pipeline of this process: (its counters, index of its
+# started-waves word, its wave count, the event behind its kernel) -- SmootherPipeline.submit_sequence
+_last_scheduled = {}
+
+
 class SmootherPipeline:
     """
     Forward passes and smoothers of consecutive batches side by side on the GPU, several of each in flight.
@@ -954,7 +959,7 @@ class SmootherPipeline:
         # -- pinned host memory above all -- is a driver call of unbounded length in the middle of a sequence of launches
         host_ws = dev_ws = counters_all = None
         for j, (cap, h, d, c) in enumerate(self._sched_free):
-            if cap >= nbytes and c.numel() >= n + 1:
+            if cap >= nbytes and c.numel() >= n + 2:
                 host_ws, dev_ws, counters_all = h, d, c
                 del self._sched_free[j]
                 break
@@ -963,16 +968,29 @@ class SmootherPipeline:
                 cap = max(1 << 20, 1 << (nbytes - 1).bit_length())
                 host_ws = torch.empty(cap, dtype=torch.uint8, pin_memory=self._sched_pinned)
                 dev_ws = torch.empty(cap, dtype=torch.uint8, device=self.device)
-                counters_all = torch.empty(max(64, n + 1), dtype=torch.int32, device=self.device)
-            counters = counters_all[:n + 1]  # [0 .. n) window_done, [n] error
-            counters.zero_()
+                counters_all = torch.empty(max(64, n + 2), dtype=torch.int32, device=self.device)
+            counters = counters_all[:n + 1]  # [0 .. n) window_done, [n] error; [n + 1]: waves of the launch that have begun
+            counters_all[:n + 2].zero_()
             zeroed = torch.cuda.Event()
             zeroed.record(fwd_stream)
+        # One scheduled launch becomes resident at a time: every wave of a launch may wait for any other, so two launches
+        # dispatched together -- this one while the one before it (of this or another pipeline) is still finding its SIMDs
+        # behind a backlog of smoother waves -- could each hold part of the chip and wait for the rest.  The launch before
+        # this one counts its waves as they begin; a one-wave gate on this launch's stream waits for all of them.
+        dkey = self.device.index or 0
+        prev = _last_scheduled.get(dkey)
+        prev_keep = None
+        if prev is not None and not prev[3].query():
+            prev_keep = prev[0]
+            binding.check(self.lib.ste_stream_wait_counter(prev[0].data_ptr() + 4 * prev[1], prev[2], counters.data_ptr() + 4 * n,
+                                                           float(timeout_s) * 4, C.c_void_p(fwd_stream.cuda_stream)),
+                          "ste_stream_wait_counter")
         sc = binding.SteFwdSchedF64()
         sc.nwindows, sc.windows, sc.slice_steps = n, C.addressof(structs), step
         sc.nwaves, sc.nrounds, sc.items = nwaves, int(items.shape[0]), items.ctypes.data
         sc.host_ws, sc.dev_ws, sc.ws_bytes = host_ws.data_ptr(), dev_ws.data_ptr(), nbytes
         sc.window_done, sc.error, sc.timeout_s = counters.data_ptr(), counters.data_ptr() + 4 * n, float(timeout_s)
+        sc.started = counters_all.data_ptr() + 4 * (n + 1)
         if timing is not None:
             timing["forward"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             timing["smoothers"] = []
@@ -986,7 +1004,8 @@ class SmootherPipeline:
         # the launch's tables and counters stay alive until the pipeline is synchronised, or every gate and smoother that
         # looks at them has finished (their error word is read then)
         events = []
-        self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events, counters_all))
+        self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events, counters_all, prev_keep))
+        _last_scheduled[dkey] = (counters_all, n + 1, nwaves, ready, id(self))
         waited = set()
         for i, db in enumerate(dbs):
             if getattr(db, "_pipeline_done", None) is None:
@@ -1056,6 +1075,8 @@ class SmootherPipeline:
             self._batches = []
             self._sched_live = []
             self._sched_free = []
+            for dkey in [k for k, v in _last_scheduled.items() if v[4] == id(self)]:  # (drained above: nothing to wait for)
+                del _last_scheduled[dkey]
             self.fwd_streams, self.bwd_streams, self._tail_stream = [], [], None
             raw, self._raw = self._raw, []
             for h in raw:

@@ -33,7 +33,7 @@ def test_struct_layout_matches_header():
         fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|int64_t|double|size_t|void|ste_ukf_batch_f64)\s*\*?\s*(\w+)\s*;", body)
         assert fields == [f[0] for f in mirror._fields_], cname
     assert C.sizeof(binding.SteUkfBatchF64) == 24 + 3 * 8 + 22 * 8 + 16 + 8 + 8 + 8  # 0.3.1: track_stride, sm_pos, 2 x int32
-    assert C.sizeof(binding.SteFwdSchedF64) == 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # 0.3.2
+    assert C.sizeof(binding.SteFwdSchedF64) == 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # 0.3.2
 
 
 def _minimal_batch(binding, keep):

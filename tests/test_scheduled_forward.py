@@ -269,3 +269,39 @@ def test_slices_that_change_waves_every_round_hand_over_bit_for_bit():
             pipe.synchronize()
             for d in seqs:
                 assert _same(ref, d), rep
+
+
+@pytest.mark.gpu
+def test_scheduled_launches_of_two_pipelines_become_resident_one_at_a_time():
+    """Every wave of a scheduled launch may wait for any other, so two launches dispatched together could each hold part of
+    the chip.  The launch counts its waves as they begin (``started``, include/ste.h) and the next scheduled launch of the
+    process -- here: of another pipeline, with nothing else ordering the two -- waits on its stream for all of them."""
+    import torch
+
+    cases = [(9000, 33, 4, 31), (7000, 33, 4, 57)]
+    refs, seqs = [], []
+    for B, nobs, sub, seed in cases:
+        _, hb = _uniform(B, 9_000_000 + seed, nobs=nobs, substeps=sub)
+        hb.lanes = 1
+        r = _clear(batch.DeviceBatch(hb))
+        r.run()
+        refs.append(r)
+        seqs.append([_clear(batch.DeviceBatch(hb)) for _ in range(8)])  # 8 x 141 / 8 x 110 tiles: more than a chip-full each
+    torch.cuda.synchronize()
+    with batch.SmootherPipeline(ntracks=9000) as pa, batch.SmootherPipeline(ntracks=7000) as pb:
+        nwaves = 4 * (pa.forward_cus - pa.reserve_cus)
+        for rep in range(3):
+            for group in seqs:
+                for d in group:
+                    _clear(d)
+            pa.submit_sequence(seqs[0])
+            first = pa._sched_live[-1]
+            pb.submit_sequence(seqs[1])
+            assert pb._sched_live[-1][8] is first[7]  # the second launch holds the first one's counters: its gate reads them
+            pb.submit_sequence(seqs[1][:3] + seqs[0][:0], smooth=False)  # (and a third behind the second, same pipeline)
+            pa.synchronize()
+            pb.synchronize()
+            assert int(first[7][len(seqs[0]) + 1].item()) == nwaves  # every wave of the launch counted itself in
+            for r, group in zip(refs, seqs):
+                for d in group:
+                    assert _same(r, d), rep
