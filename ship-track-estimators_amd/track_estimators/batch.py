@@ -683,6 +683,12 @@ class SmootherPipeline:
         (seven at 10 000 tracks), ``smoother_streams`` smoothers hide each other's latency (six).
     ``shared=False``  round 1-2's split: forward passes on the first ``forward_cus`` compute units, smoothers on the rest.
 
+    ``sequence_only=True``: a pipeline that will only see ``submit_sequence`` (one scheduled forward launch per sequence)
+    keeps one forward stream.  Every stream here is a hardware queue, the device has about two dozen for everything that
+    runs on it (measured: this pipeline's 14 plus nine idle ones elsewhere in the process and launches start to take turns),
+    and scheduled launches -- long-lived kernels beside one-wave gates that never leave their queues idle -- are the first
+    to suffer when they run out.
+
     Each ``DeviceBatch`` owns its histories and work rows; a batch is not resubmitted before its previous smoother has
     finished (events), so the caller rotates through ``buffers_needed`` or more of them.
 
@@ -698,7 +704,7 @@ class SmootherPipeline:
 
     def __init__(self, device="cuda:0", forward_cus: Optional[int] = None, ntracks: Optional[int] = None,
                  forward_streams: Optional[int] = None, smoother_streams: Optional[int] = None, forward_lanes: int = 1,
-                 shared: Optional[bool] = None, reserve_cus: int = 0, slices: Optional[int] = None):
+                 shared: Optional[bool] = None, reserve_cus: int = 0, slices: Optional[int] = None, sequence_only: bool = False):
         import torch
 
         self.torch = torch
@@ -746,6 +752,10 @@ class SmootherPipeline:
             # fewer forward passes and needs as few smoothers beside them (and each buffer set is the larger for it:
             # 224 + 240 B per track-step, 23 GB at 100 000 x 500): never more smoother streams than forward streams, at least two.
             smoother_streams = max(2, min(6, forward_streams)) if shared else 2
+        if sequence_only:
+            # a pipeline for submit_sequence alone: a scheduled launch is one kernel on one stream however many windows it
+            # covers, and every stream not created is a hardware queue left to whatever else runs on the device
+            forward_streams = 1
         if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
@@ -1330,7 +1340,13 @@ def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = T
     B = db.ntracks
     wins = fleet_windows(B, chunk)
     own_pipe = pipeline is None
-    pipe = pipeline or SmootherPipeline(dev, ntracks=wins[0][1] - wins[0][0], slices=slices)
+    if scheduled is None:
+        scheduled = (resident and 1 < len(wins) <= SCHEDULED_FLEET_MAX_WINDOWS and (pipeline is None or pipeline.forward_lanes != 4))
+    # (a pipeline built for ONE scheduled launch needs one forward stream: every stream is a hardware queue, the device has
+    #  about two dozen for everything that runs on it, and scheduled launches are the first to suffer when they run out --
+    #  DESIGN.md section 5)
+    pipe = pipeline or SmootherPipeline(dev, ntracks=wins[0][1] - wins[0][0], slices=slices,
+                                        sequence_only=bool(scheduled and resident and len(wins) > 1))
     inv = None
     if hb.order is not None:  # back to the caller's track order
         inv = np.empty_like(hb.order)
@@ -1347,8 +1363,6 @@ def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = T
                 attr, width = DeviceBatch._OUT[name]
                 host[name] = torch.empty((B, hb.Nmax + 1, width), dtype=torch.float64, pin_memory=True)
         keep = []
-        if scheduled is None:
-            scheduled = resident and 1 < len(wins) <= SCHEDULED_FLEET_MAX_WINDOWS and pipe.forward_lanes != 4
         if scheduled and resident and len(wins) > 1:
             ws = [db.window(lo, hi) for lo, hi in wins]
             dones = pipe.submit_sequence(ws, smooth=smooth)
