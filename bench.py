@@ -613,8 +613,10 @@ def _main(stack):
         run_steps(prepass)
         drain()
     # auto: the two launch forms give the same bits, so the choice between them is made by the clock, untimed, on this box now
-    # (twice each, the better of the two): a scheduled launch has more in front of it than a per-step one (a table upload, the
-    # clearing of its counters), and on one of the boxes of round 5 that cost 10 ms per launch for tens of seconds at a time
+    # (twice each, the better of the two): scheduled launches -- a long-lived grid beside one-wave gates that never leave their
+    # queues idle -- are the first to suffer when the device runs out of hardware queues (this pipeline holds 14 of about 24;
+    # on three boxes of round 5 something else on the device held the rest for a while, and scheduled launches took twice
+    # their time while per-step launches kept theirs: DESIGN.md section 5)
     auto_choice = None
     if seq and args.sequence == "auto":
         def wall(n):

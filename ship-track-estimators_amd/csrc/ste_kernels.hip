@@ -1007,8 +1007,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // Table upload of a scheduled launch as a kernel on the launch's own stream: copies `ncopy` 16-byte words from page-locked host
 // memory (read over the host link) into the device workspace and clears the `nzero` words behind them (the progress counters).
-// A copy-engine transfer in front of every scheduled launch is an engine shared with whatever else the node is doing: on one
-// box the 0.3 MB transfer took ~10 ms for tens of seconds at a time (profiles/r05_scheduled_forward.txt).
+// Nothing but kernels of this stream between two launches: no copy-engine transfer (an engine, and a queue, shared with
+// whatever else the node is doing) in front of every scheduled launch.
 __global__ __launch_bounds__(256) void sched_upload(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t ncopy, size_t nzero) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncopy + nzero; i += stride)
