@@ -394,7 +394,8 @@ def _main(stack):
                          "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
                          "step, or 'auto'.  auto, one GPU and --steps <= 40 (a short run is all fill and drain, which a schedule "
                          "shortens): two scheduled launches -- the first of as many steps as fill the chip once -- and one launch "
-                         "per step are both run untimed and the faster form is used (config.sequence_auto says which: 0.77-0.79 "
+                         "per step are both run untimed, each on the pipeline it needs (2 + 6 + 1 against 7 + 6 + 1 streams), and "
+                         "the faster form is used (config.sequence_auto says which: 0.74-0.77 "
                          "against 0.80 ms per step at the driver's 20 steps); longer runs and runs with an exchange: one launch "
                          "per step (in the steady state per-step launches re-balance by themselves and are 1-2 %% faster; "
                          "DESIGN.md section 5)")
@@ -626,20 +627,31 @@ def _main(stack):
             drain()
             return (time.perf_counter() - tw) * 1e3
 
-        keep = seq
+        # Each form on the pipeline it needs, one pipeline alive at a time: per-step launches on the 7 + 6 + 1 streams built
+        # above; scheduled launches on 2 + 6 + 1 (sequence_only) -- five hardware queues fewer to hold while they run.
+        keep, seq = seq, 0
+        step_ms = min(wall(args.steps) for _ in range(2))
+        pipe.close()
+        pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **dict(kw, sequence_only=True)))
+        seq = keep
         try:
+            wall(args.steps)  # (this pipeline's first launches: schedules, workspaces)
             sched_ms = min(wall(args.steps) for _ in range(2))
         except binding.SteError as exc:
             print(f"[bench] scheduled forward launches disabled after an error in the untimed comparison: {exc}", file=sys.stderr, flush=True)
             torch.cuda.synchronize(dev)
             sched_ms = float("inf")
-        seq = 0
-        step_ms = min(wall(args.steps) for _ in range(2))
-        seq = keep if sched_ms <= step_ms else 0
+        if not sched_ms <= step_ms:
+            seq = 0
+            pipe.close()
+            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
+            wall(prepass)
         auto_choice = {"scheduled_launches_ms": sched_ms if np.isfinite(sched_ms) else None, "per_step_launches_ms": step_ms,
                        "steps": args.steps, "chosen": "scheduled" if seq else "per_step",
-                       "note": "untimed, before the warm-up: wall time of --steps steps in either launch form (better of two runs "
-                               "each); the timed region uses the faster form -- both give the same histories bit for bit"}
+                       "streams": f"{len(pipe.fwd_streams)} forward + {len(pipe.bwd_streams)} smoother + 1",
+                       "note": "untimed, before the warm-up: wall time of --steps steps in either launch form, each on the "
+                               "pipeline it needs (better of two runs each); the timed region uses the faster form -- both "
+                               "give the same histories bit for bit"}
     run_steps(args.warmup)
     drain()
     if dist is not None:

@@ -684,7 +684,7 @@ class SmootherPipeline:
     ``shared=False``  round 1-2's split: forward passes on the first ``forward_cus`` compute units, smoothers on the rest.
 
     ``sequence_only=True``: a pipeline that will only see ``submit_sequence`` (one scheduled forward launch per sequence)
-    keeps one forward stream.  Every stream here is a hardware queue, the device has about two dozen for everything that
+    keeps two forward streams.  Every stream here is a hardware queue, the device has about two dozen for everything that
     runs on it (measured: this pipeline's 14 plus nine idle ones elsewhere in the process and launches start to take turns),
     and scheduled launches -- long-lived kernels beside one-wave gates that never leave their queues idle -- are the first
     to suffer when they run out.
@@ -754,8 +754,9 @@ class SmootherPipeline:
             smoother_streams = max(2, min(6, forward_streams)) if shared else 2
         if sequence_only:
             # a pipeline for submit_sequence alone: a scheduled launch is one kernel on one stream however many windows it
-            # covers, and every stream not created is a hardware queue left to whatever else runs on the device
-            forward_streams = 1
+            # covers (two streams: the next sequence's launch starts as the waves of this one leave), and every stream not
+            # created is a hardware queue left to whatever else runs on the device
+            forward_streams = min(forward_streams, 2)
         if not (0 < forward_cus < ncu) and not shared:
             raise ValueError(f"forward_cus must be in 1..{ncu - 1} (got {forward_cus}): the smoother needs CUs of its own")
         if forward_streams < 1 or smoother_streams < 1:
@@ -1342,7 +1343,7 @@ def run_fleet(fleet, chunk: int = FLEET_CHUNK, device="cuda:0", smooth: bool = T
     own_pipe = pipeline is None
     if scheduled is None:
         scheduled = (resident and 1 < len(wins) <= SCHEDULED_FLEET_MAX_WINDOWS and (pipeline is None or pipeline.forward_lanes != 4))
-    # (a pipeline built for ONE scheduled launch needs one forward stream: every stream is a hardware queue, the device has
+    # (a pipeline built for scheduled launches needs two forward streams, not seven: every stream is a hardware queue, the device has
     #  about two dozen for everything that runs on it, and scheduled launches are the first to suffer when they run out --
     #  DESIGN.md section 5)
     pipe = pipeline or SmootherPipeline(dev, ntracks=wins[0][1] - wins[0][0], slices=slices,

@@ -288,7 +288,8 @@ def test_scheduled_launches_of_two_pipelines_become_resident_one_at_a_time():
         refs.append(r)
         seqs.append([_clear(batch.DeviceBatch(hb)) for _ in range(8)])  # 8 x 141 / 8 x 110 tiles: more than a chip-full each
     torch.cuda.synchronize()
-    with batch.SmootherPipeline(ntracks=9000) as pa, batch.SmootherPipeline(ntracks=7000) as pb:
+    # (sequence_only: one forward stream each -- two full pipelines would hold 28 of the device's ~24 hardware queues)
+    with batch.SmootherPipeline(ntracks=9000, sequence_only=True) as pa, batch.SmootherPipeline(ntracks=7000, sequence_only=True) as pb:
         nwaves = 4 * (pa.forward_cus - pa.reserve_cus)
         for rep in range(3):
             for group in seqs:
