@@ -394,8 +394,8 @@ def _main(stack):
                          "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
                          "step, or 'auto'.  auto, one GPU and --steps <= 40 (a short run is all fill and drain, which a schedule "
                          "shortens): two scheduled launches -- the first of as many steps as fill the chip once -- and one launch "
-                         "per step are both run untimed, each on the pipeline it needs (2 + 6 + 1 against 7 + 6 + 1 streams), and "
-                         "the faster form is used (config.sequence_auto says which: 0.74-0.77 "
+                         "per step are both run untimed, each on the pipeline it needs (2 + 6 + 1 against 7 + 6 + 1 streams; three runs, "
+                         "the slowest counts), and the faster form is used (config.sequence_auto says which: 0.74-0.77 "
                          "against 0.80 ms per step at the driver's 20 steps); longer runs and runs with an exchange: one launch "
                          "per step (in the steady state per-step launches re-balance by themselves and are 1-2 %% faster; "
                          "DESIGN.md section 5)")
@@ -614,7 +614,7 @@ def _main(stack):
         run_steps(prepass)
         drain()
     # auto: the two launch forms give the same bits, so the choice between them is made by the clock, untimed, on this box now
-    # (twice each, the better of the two): scheduled launches -- a long-lived grid beside one-wave gates that never leave their
+    # (three runs each): scheduled launches -- a long-lived grid beside one-wave gates that never leave their
     # queues idle -- are the first to suffer when the device runs out of hardware queues (this pipeline holds 14 of about 24;
     # on three boxes of round 5 something else on the device held the rest for a while, and scheduled launches took twice
     # their time while per-step launches kept theirs: DESIGN.md section 5)
@@ -629,29 +629,34 @@ def _main(stack):
 
         # Each form on the pipeline it needs, one pipeline alive at a time: per-step launches on the 7 + 6 + 1 streams built
         # above; scheduled launches on 2 + 6 + 1 (sequence_only) -- five hardware queues fewer to hold while they run.
+        # (decided by the SLOWEST of three runs of either form: at the edge of the device's queue slots a form is fast in
+        #  one run and twice as slow in the next, and the timed region is one run)
         keep, seq = seq, 0
-        step_ms = min(wall(args.steps) for _ in range(2))
+        step_all = sorted(wall(args.steps) for _ in range(3))
+        step_ms = step_all[-1]
         pipe.close()
         pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **dict(kw, sequence_only=True)))
         seq = keep
         try:
             wall(args.steps)  # (this pipeline's first launches: schedules, workspaces)
-            sched_ms = min(wall(args.steps) for _ in range(2))
+            sched_all = sorted(wall(args.steps) for _ in range(3))
+            sched_ms = sched_all[-1]
         except binding.SteError as exc:
             print(f"[bench] scheduled forward launches disabled after an error in the untimed comparison: {exc}", file=sys.stderr, flush=True)
             torch.cuda.synchronize(dev)
-            sched_ms = float("inf")
+            sched_all, sched_ms = None, float("inf")
         if not sched_ms <= step_ms:
             seq = 0
             pipe.close()
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
             wall(prepass)
         auto_choice = {"scheduled_launches_ms": sched_ms if np.isfinite(sched_ms) else None, "per_step_launches_ms": step_ms,
+                       "scheduled_launches_ms_all": sched_all, "per_step_launches_ms_all": step_all,
                        "steps": args.steps, "chosen": "scheduled" if seq else "per_step",
                        "streams": f"{len(pipe.fwd_streams)} forward + {len(pipe.bwd_streams)} smoother + 1",
                        "note": "untimed, before the warm-up: wall time of --steps steps in either launch form, each on the "
-                               "pipeline it needs (better of two runs each); the timed region uses the faster form -- both "
-                               "give the same histories bit for bit"}
+                               "pipeline it needs (three runs each, the slowest counts); the timed region uses the faster "
+                               "form -- both give the same histories bit for bit"}
     run_steps(args.warmup)
     drain()
     if dist is not None:

@@ -465,10 +465,13 @@ def test_bench_line_carries_the_contract():
     # tiles do not fill the chip: ONE scheduled launch), and the line says which it took and what either cost
     auto = out["config"]["sequence_auto"]
     assert auto["steps"] == 30 and auto["per_step_launches_ms"] > 0 and auto["scheduled_launches_ms"] > 0
+    # three untimed runs of either form, the slowest decides; the scheduled form ran on a pipeline of its own (2 forward streams)
+    assert len(auto["per_step_launches_ms_all"]) == 3 and max(auto["per_step_launches_ms_all"]) == auto["per_step_launches_ms"]
+    assert len(auto["scheduled_launches_ms_all"]) == 3 and max(auto["scheduled_launches_ms_all"]) == auto["scheduled_launches_ms"]
     if auto["chosen"] == "scheduled":
         assert auto["scheduled_launches_ms"] <= auto["per_step_launches_ms"]
         assert pl["steps_per_launch"] == 30 and out["config"]["steps_per_scheduled_forward_launch"] == [30]
-        assert [d["steps"] for d in out["kernels_ms"]["scheduled_launches"]] == [30]
+        assert [d["steps"] for d in out["kernels_ms"]["scheduled_launches"]] == [30] and auto["streams"].startswith("2 forward")
     else:
         assert auto["chosen"] == "per_step" and auto["scheduled_launches_ms"] > auto["per_step_launches_ms"]
         assert pl["steps_per_launch"] == 1 and out["config"]["steps_per_scheduled_forward_launch"] == 0
