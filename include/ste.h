@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define STE_VERSION 320 /* 0.3.2: the forward passes of many windows as one scheduled launch (ste_ukf_forward_sched_f64,
+#define STE_VERSION 321 /* 0.3.2: the forward passes of many windows as one scheduled launch (ste_ukf_forward_sched_f64,
                            ste_stream_wait_counter).  0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in
                            time slices (step_begin / step_end).  0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma
                            weights sum to one */
@@ -249,6 +249,35 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream);
 
 /* Holds `stream` (a one-wave kernel) until *counter >= need; after timeout_s (0 = 2 s) it gives up and sets *error = 2. */
 int ste_stream_wait_counter(const int32_t* counter, int32_t need, int32_t* error, double timeout_s, void* stream);
+
+/* The smoothers of every window of a scheduled forward launch as ONE launch: a wave per (window, 64-track tile) that waits
+ * (bounded; *error = 2) until the forward launch has finished THAT tile's last slice and then smooths it -- the reference's
+ * run_rts_smoother (kalman_filter.py:119-137) per track, started as soon as the track's forward pass is complete instead of
+ * when its whole window's is.  `items` lists every tile of every window once, in the order the forward schedule finishes
+ * them (waves are dispatched in that order).  `progress` is the forward launch's per-tile slice counter array: dev_ws of that
+ * launch + ste_ukf_forward_sched_progress_offset(same arguments as ste_ukf_forward_sched_workspace).  Every window must take
+ * the one-kernel smoother (rts_work; more than 4096 tracks, or tuning bit 10) and agree on sog_rate_rts / cog_rate_rts.
+ * Waiting waves hold a wave slot each: put ste_stream_wait_counter(started of the forward launch, its nwaves, ...) on `stream`
+ * in front of this call, so that every forward wave has its SIMD before a waiting smoother wave could be in its way.  Results
+ * are those of ste_urtss_backward_f64 on every window, bit for bit. */
+typedef struct ste_bwd_sched_f64 {
+    int32_t nwindows;
+    const ste_ukf_batch_f64* windows; /* HOST [nwindows], the forward launch's windows */
+    int32_t slice_steps;              /* as in the forward launch */
+    int32_t nitems;                   /* tiles of all windows */
+    const int32_t* items;             /* HOST [nitems][2]: (window, tile of that window) */
+    void* host_ws;                    /* HOST scratch (page-locked if possible), ws_bytes (ste_urtss_backward_sched_workspace) */
+    void* dev_ws;                     /* DEVICE scratch, ws_bytes */
+    size_t ws_bytes;
+    const int32_t* progress;          /* DEVICE: the forward launch's per-tile slice counters */
+    int32_t* error;                   /* DEVICE [1]: the forward launch's error word */
+    double timeout_s;                 /* bound of a wave's wait; 0 = 2 s */
+} ste_bwd_sched_f64;
+
+size_t ste_ukf_forward_sched_progress_offset(int32_t nwindows, int32_t max_slices, int64_t ntiles_total, int32_t nrounds,
+                                             int32_t nwaves);
+size_t ste_urtss_backward_sched_workspace(int32_t nwindows, int64_t ntiles_total);
+int ste_urtss_backward_sched_f64(const ste_bwd_sched_f64* sc, void* stream);
 
 /* Unscented RTS smoother: reads fwd_mean/fwd_cov, writes sm_mean/sm_cov, ORs status. */
 int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream);

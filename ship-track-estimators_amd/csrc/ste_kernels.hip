@@ -1732,9 +1732,8 @@ __device__ __forceinline__ int smoother_step_gain(const KParams& p, int k, size_
 
 // kShift: the smoother has rates of its own (sog_rate_rts / cog_rate_rts); compiled out for batches that share them.
 template <bool kShift>
-__global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
+__device__ __forceinline__ void smooth_tile_l1(const KParams& p, const size_t t) {
     const size_t B = (size_t)p.ld;
-    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= (size_t)p.B) return;
     const int ns = p.nsteps ? p.nsteps[t] : p.Nmax;
     const bool always_full = p.noise_pred || p.noise_upd || p.noise_rts;
@@ -1833,6 +1832,44 @@ __global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
     for (int e = 0; e < 10; ++e) chk += Ps[e] * 0.0;
     if (!(chk == 0.0)) st |= STE_STATUS_NAN;
     if (st) atomicOr(&p.status[t], st);
+}
+
+template <bool kShift>
+__global__ __launch_bounds__(64) void urtss_recur_l1(const KParams p) {
+    smooth_tile_l1<kShift>(p, (size_t)blockIdx.x * 64 + threadIdx.x);
+}
+
+// The smoothers of every window of a scheduled forward launch as ONE launch (ste_urtss_backward_sched_f64): a wave per
+// (window, 64-track tile), in the order the schedule finishes the tiles, each waiting (bounded) for ITS tile's last slice
+// -- a tile is smoothed as soon as it has been filtered, not when the last tile of its window has.  The body is
+// urtss_recur_l1's.  Waves that wait hold a wave slot each: the launch goes behind a gate on the forward launch's started-wave
+// count, so that every forward wave has its SIMD before a waiting smoother wave could be in its way (include/ste.h).
+struct SmoothItem {
+    int kp;    // index of the window's parameter block
+    int tile;  // 64-track tile of that window
+    int prog;  // index of the tile's progress counter (the forward launch's)
+    int need;  // slices of a forward pass of that window: the count the tile's counter reaches
+};
+struct SmoothSchedParams {
+    const KParams* kps;
+    const SmoothItem* items;
+    const int* progress;
+    int* error;  // 2 = a smoother wave waited longer than its bound
+    unsigned long long timeout_ticks;
+};
+template <bool kShift>
+__global__ __launch_bounds__(64) void urtss_recur_sched(const SmoothSchedParams sp) {
+    typedef const KParams __attribute__((address_space(4))) ConstKParams;
+    const SmoothItem* ip = sp.items + blockIdx.x;
+    const int kp = __builtin_amdgcn_readfirstlane(ip->kp), tile = __builtin_amdgcn_readfirstlane(ip->tile);
+    const int prog = __builtin_amdgcn_readfirstlane(ip->prog), need = __builtin_amdgcn_readfirstlane(ip->need);
+    if (__hip_atomic_load(sp.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+        !sched_wait(sp.progress + prog, need, sp.timeout_ticks)) {
+        if (threadIdx.x == 0) __hip_atomic_store(sp.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const KParams& p = *(const KParams*)(ConstKParams*)(uintptr_t)(sp.kps + kp);
+    smooth_tile_l1<kShift>(p, (size_t)tile * 64 + threadIdx.x);
 }
 
 
@@ -2532,6 +2569,27 @@ SchedLayout sched_layout(size_t nkp, size_t nitems, size_t ntiles) {
     return l;
 }
 
+// `ncopy` bytes of a schedule's table from the caller's host workspace into the device workspace and `nzero` zero bytes behind
+// them (multiples of 16).  Page-locked host memory: a kernel on `s` reads it in place (no copy engine between two launches);
+// anything else: a staged copy.
+int upload_table(char* dw, const char* hw, size_t ncopy, size_t nzero, hipStream_t s, const char* what) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const bool locked = hipPointerGetAttributes(&attr, hw) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer &&
+                        ((uintptr_t)attr.devicePointer & 15) == 0 && ((uintptr_t)dw & 15) == 0;
+    if (locked) {
+        const size_t nwords = (ncopy + nzero) / 16;
+        const unsigned blocks = (unsigned)std::min<size_t>(256, (nwords + 255) / 256);
+        hipLaunchKernelGGL(ste::sched_upload, dim3(blocks), dim3(256), 0, s, (uint4*)dw, (const uint4*)attr.devicePointer, ncopy / 16,
+                           nzero / 16);
+        return check_hip(hipGetLastError(), what);
+    }
+    (void)hipGetLastError();  // (the attribute query of pageable memory reports an error: not this call's)
+    int rc = check_hip(hipMemcpyAsync(dw, hw, ncopy, hipMemcpyHostToDevice, s), what);
+    if (rc || !nzero) return rc;
+    return check_hip(hipMemsetAsync(dw + ncopy, 0, nzero, s), what);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2730,24 +2788,7 @@ int ste_ukf_forward_sched_f64(const ste_fwd_sched_f64* sc, void* stream) {
     if (sc->nwaves > 4 * ncu) return fail(STE_EINVAL, "scheduled forward pass: nwaves exceeds the device's SIMD count (4 per compute unit)");
     hipStream_t s = (hipStream_t)stream;
     char* dw = (char*)sc->dev_ws;
-    // page-locked host_ws: a kernel on `s` reads it in place (no copy engine between two launches); anything else: a staged copy
-    hipPointerAttribute_t attr;
-    memset(&attr, 0, sizeof(attr));
-    const bool locked = hipPointerGetAttributes(&attr, hw) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer &&
-                        ((uintptr_t)attr.devicePointer & 15) == 0 && ((uintptr_t)dw & 15) == 0;
-    int rc = STE_OK;
-    if (locked) {
-        const size_t nwords = lay.total / 16;
-        const unsigned blocks = (unsigned)std::min<size_t>(256, (nwords + 255) / 256);
-        hipLaunchKernelGGL(ste::sched_upload, dim3(blocks), dim3(256), 0, s, (uint4*)dw, (const uint4*)attr.devicePointer,
-                           lay.progress / 16, (lay.total - lay.progress) / 16);
-        rc = check_hip(hipGetLastError(), "scheduled forward pass: table upload");
-    } else {
-        (void)hipGetLastError();  // (the attribute query of pageable memory reports an error: not this call's)
-        rc = check_hip(hipMemcpyAsync(dw, hw, lay.progress, hipMemcpyHostToDevice, s), "scheduled forward pass: table upload");
-        if (rc) return rc;
-        rc = check_hip(hipMemsetAsync(dw + lay.progress, 0, lay.total - lay.progress, s), "scheduled forward pass: counters");
-    }
+    int rc = upload_table(dw, hw, lay.progress, lay.total - lay.progress, s, "scheduled forward pass: table upload");
     if (rc) return rc;
     ste::SchedParams sp;
     sp.kps = (const ste::KParams*)(dw + lay.kps);
@@ -2776,6 +2817,86 @@ int ste_stream_wait_counter(const int32_t* counter, int32_t need, int32_t* error
     hipLaunchKernelGGL(ste::sched_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)counter, (int)need, (int*)error,
                        (unsigned long long)((timeout_s > 0 ? timeout_s : 2.0) * 1e8));
     return check_hip(hipGetLastError(), "sched_gate launch");
+}
+
+size_t ste_ukf_forward_sched_progress_offset(int32_t nwindows, int32_t max_slices, int64_t ntiles_total, int32_t nrounds,
+                                             int32_t nwaves) {
+    if (nwindows < 0 || max_slices < 0 || ntiles_total < 0 || nrounds < 0 || nwaves < 0) return 0;
+    return sched_layout((size_t)nwindows * ((size_t)max_slices * ((size_t)max_slices + 1) / 2), (size_t)nrounds * (size_t)nwaves,
+                        (size_t)ntiles_total).progress;
+}
+
+size_t ste_urtss_backward_sched_workspace(int32_t nwindows, int64_t ntiles_total) {
+    if (nwindows < 0 || ntiles_total < 0) return 0;
+    return align16((size_t)nwindows * sizeof(ste::KParams)) + align16((size_t)ntiles_total * sizeof(ste::SmoothItem));
+}
+
+int ste_urtss_backward_sched_f64(const ste_bwd_sched_f64* sc, void* stream) {
+    if (!sc) return fail(STE_EINVAL, "schedule pointer is NULL");
+    if (sc->nwindows < 1 || !sc->windows) return fail(STE_EINVAL, "scheduled smoother: nwindows >= 1 and windows are required");
+    if (sc->nitems < 1 || !sc->items) return fail(STE_EINVAL, "scheduled smoother: nitems >= 1 and items are required");
+    if (!sc->host_ws || !sc->dev_ws || !sc->progress || !sc->error)
+        return fail(STE_EINVAL, "scheduled smoother: host_ws, dev_ws, progress and error are required");
+    const int step = sc->slice_steps ? sc->slice_steps : STE_SLICE_ALIGN;
+    if (step < STE_SLICE_ALIGN || step % STE_SLICE_ALIGN != 0)
+        return fail(STE_EINVAL, "scheduled smoother: slice_steps must be a positive multiple of STE_SLICE_ALIGN (64)");
+    const size_t kp_bytes = align16((size_t)sc->nwindows * sizeof(ste::KParams));
+    const size_t total = kp_bytes + align16((size_t)sc->nitems * sizeof(ste::SmoothItem));
+    if (sc->ws_bytes < total) return fail(STE_EINVAL, "scheduled smoother: workspace too small (ste_urtss_backward_sched_workspace)");
+    char* hw = (char*)sc->host_ws;
+    ste::KParams* kps = (ste::KParams*)hw;
+    std::vector<int> nslices((size_t)sc->nwindows), tile0((size_t)sc->nwindows + 1);
+    size_t ntiles = 0;
+    int shift = -1;
+    for (int w = 0; w < sc->nwindows; ++w) {
+        const ste_ukf_batch_f64& b = sc->windows[w];
+        if (b.B <= 0 || b.Nmax <= 0) return fail(STE_EINVAL, "scheduled smoother: a window has B <= 0 or Nmax <= 0");
+        if (b.step_begin != 0 || b.step_end != 0) return fail(STE_EINVAL, "scheduled smoother: windows must not carry a step range of their own");
+        int rc = make_params(&b, true, true, kps + w);
+        if (rc) return rc;
+        const ste::KParams& kp = kps[w];
+        // one kernel runs every window: the one-kernel smoother from the forward pass's work rows (what launch_backward picks
+        // for a batch of more than kLeanSmootherMaxTracks tracks), with or without rates of its own
+        if (!kp.rts_work || (kp.tuning & 0x200) || (!(kp.tuning & 0x400) && kp.B <= kLeanSmootherMaxTracks))
+            return fail(STE_EINVAL, "scheduled smoother: every window must take the one-kernel smoother (rts_work, more than 4096 tracks or tuning bit 10)");
+        const int sh = (kp.sog_rate_rts || kp.cog_rate_rts) ? 1 : 0;
+        if (shift >= 0 && sh != shift) return fail(STE_EINVAL, "scheduled smoother: the windows must agree on smoother rates (one kernel runs them all)");
+        shift = sh;
+        nslices[w] = std::max(1, (b.Nmax + step - 1) / step);
+        tile0[w] = (int)ntiles;
+        ntiles += ((size_t)b.B + 63) / 64;
+        if (ntiles > 0x7fffffff) return fail(STE_EINVAL, "scheduled smoother: too many tiles");
+    }
+    tile0[sc->nwindows] = (int)ntiles;
+    if ((size_t)sc->nitems != ntiles) return fail(STE_EINVAL, "scheduled smoother: items must name every tile of every window once");
+    ste::SmoothItem* items = (ste::SmoothItem*)(hw + kp_bytes);
+    std::vector<char> seen(ntiles, 0);
+    for (int i = 0; i < sc->nitems; ++i) {
+        const int w = sc->items[2 * i], t = sc->items[2 * i + 1];
+        if (w < 0 || w >= sc->nwindows || t < 0 || t >= tile0[w + 1] - tile0[w])
+            return fail(STE_EINVAL, "scheduled smoother: an item names a window or tile that does not exist");
+        if (seen[(size_t)(tile0[w] + t)]) return fail(STE_EINVAL, "scheduled smoother: a tile appears twice");
+        seen[(size_t)(tile0[w] + t)] = 1;
+        items[i].kp = w;
+        items[i].tile = t;
+        items[i].prog = tile0[w] + t;
+        items[i].need = nslices[w];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char* dw = (char*)sc->dev_ws;
+    int rc = upload_table(dw, hw, total, 0, s, "scheduled smoother: table upload");
+    if (rc) return rc;
+    ste::SmoothSchedParams sp;
+    sp.kps = (const ste::KParams*)dw;
+    sp.items = (const ste::SmoothItem*)(dw + kp_bytes);
+    sp.progress = sc->progress;
+    sp.error = sc->error;
+    sp.timeout_ticks = (unsigned long long)((sc->timeout_s > 0 ? sc->timeout_s : 2.0) * 1e8);
+    if (shift)
+        hipLaunchKernelGGL(ste::urtss_recur_sched<true>, dim3((unsigned)sc->nitems), dim3(64), 0, s, sp);
+    else
+        hipLaunchKernelGGL(ste::urtss_recur_sched<false>, dim3((unsigned)sc->nitems), dim3(64), 0, s, sp);
+    return check_hip(hipGetLastError(), "urtss_recur_sched launch");
 }
 
 int ste_urtss_backward_f64(const ste_ukf_batch_f64* b, void* stream) {

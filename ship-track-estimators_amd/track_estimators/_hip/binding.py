@@ -99,6 +99,24 @@ class SteFwdSchedF64(C.Structure):
     ]
 
 
+class SteBwdSchedF64(C.Structure):
+    """Mirror of ``struct ste_bwd_sched_f64`` (include/ste.h)."""
+
+    _fields_ = [
+        ("nwindows", C.c_int32),
+        ("windows", _dp),
+        ("slice_steps", C.c_int32),
+        ("nitems", C.c_int32),
+        ("items", _dp),
+        ("host_ws", _dp),
+        ("dev_ws", _dp),
+        ("ws_bytes", C.c_size_t),
+        ("progress", _dp),
+        ("error", _dp),
+        ("timeout_s", C.c_double),
+    ]
+
+
 class SteGpBatchF64(C.Structure):
     """Mirror of ``struct ste_gp_batch_f64`` (include/ste.h)."""
 
@@ -161,6 +179,9 @@ SYMBOLS = {
     "ste_ukf_forward_sched_workspace": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
     "ste_ukf_forward_sched_f64": (C.c_int, [C.POINTER(SteFwdSchedF64), C.c_void_p]),
     "ste_stream_wait_counter": (C.c_int, [_dp, C.c_int32, _dp, C.c_double, C.c_void_p]),
+    "ste_ukf_forward_sched_progress_offset": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "ste_urtss_backward_sched_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "ste_urtss_backward_sched_f64": (C.c_int, [C.POINTER(SteBwdSchedF64), C.c_void_p]),
     "ste_geodetic_dynamics_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_void_p]),
     "ste_ukf_predict_f64": (C.c_int, [C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
                                       _dp, _dp, _dp, C.c_void_p]),

@@ -773,6 +773,8 @@ class SmootherPipeline:
         self._sched_live = []  # workspaces / counters of scheduled launches not yet synchronised
         self._sched_free = []  # ... and of retired ones, kept for the next launch: no allocator call on the launch path
         self._sched_pinned = True  # page-locked host workspaces: the table is uploaded by a kernel (False: staged copy; tests)
+        self._sched_free_bwd = []  # the same for the tables of the sequences' smoother launches
+        self._sched_tile_smoothers = True  # one smoother launch per sequence, a wave per tile (False: a launch per window; tests)
         self.buffers_needed = forward_streams + smoother_streams + 1
         # time slices per forward pass (DeviceBatch.forward): the waves of the passes in flight re-balance over the SIMDs at
         # every slice boundary instead of once per pass (3.6-4.5 ms at 500 steps) -- what a short sequence of batches, or
@@ -896,7 +898,8 @@ class SmootherPipeline:
 
     # -- many batches (or windows of a fleet) as ONE scheduled forward launch ---------------------------------------------
     def submit_sequence(self, dbs: Sequence["DeviceBatch"], smooth: bool = True, after_smoother=None, timing=None,
-                        final: bool = True, stagger: float = 0.0, slice_steps: int = 0, timeout_s: float = 4.0):
+                        final: bool = True, stagger: float = 0.0, slice_steps: int = 0, timeout_s: float = 4.0,
+                        tile_smoothers: Optional[bool] = None):
         """Queue forward + smoother of every batch of ``dbs`` -- distinct buffer sets, or the windows of one resident fleet --
         with ALL their forward passes as one launch of resident waves that work through a schedule of (64-track tile, time
         slice) items (``forward_schedule``; include/ste.h: ``ste_ukf_forward_sched_f64``).  One launch per batch makes a
@@ -909,6 +912,10 @@ class SmootherPipeline:
         timing events around the scheduled launch and ``smoothers`` = (start, end) around the smoother of every
         ``timing["every"]``-th batch (default 4: every record is a packet on the stream's queue between two launches).
         ``final``: nothing follows this sequence: its last smoother gets the unrestricted stream.
+        ``tile_smoothers``: the smoothers of the whole sequence as ONE launch, a wave per 64-track tile that waits for its own
+        tile's forward pass (``ste_urtss_backward_sched_f64``) instead of a gate and a launch per batch; needs batches of more
+        than 4 096 tracks (the one-kernel smoother) and no ``after_smoother``.  Default: when ``final`` and no scheduled launch
+        is in flight in front of this one (a job that is one sequence: a fleet, a short run).  Same bits either way.
         Returns the list of the batches' completion events."""
         torch = self.torch
         if self.closed:
@@ -1017,6 +1024,74 @@ class SmootherPipeline:
         events = []
         self._sched_live.append((host_ws, dev_ws, counters, structs, items, [ready], events, counters_all, prev_keep))
         _last_scheduled[dkey] = (counters_all, n + 1, nwaves, ready, id(self))
+        # One smoother launch for the whole sequence, a wave per tile that waits for ITS tile's forward pass (include/ste.h:
+        # ste_urtss_backward_sched_f64) -- when every window takes the one-kernel smoother and nothing has to happen behind
+        # individual windows; otherwise a gate and a smoother launch per window (below).
+        lean = 4096  # launch_backward's bound (csrc/ste_kernels.hip: kLeanSmootherMaxTracks)
+        if tile_smoothers is None:
+            # measured (profiles/r05_scheduled_forward.txt): ONE sequence of 20 batches 14.5-14.7 ms with tile smoothers against
+            # 15.0-15.5 with a smoother per window, a fleet the same either way; sequences that overlap (7 + 13) 15.1-15.3
+            # against 14.5-14.7 -- so: when nothing follows this sequence and none is in flight before it
+            tile_smoothers = self._sched_tile_smoothers and final and prev_keep is None
+        merged = (smooth and after_smoother is None and tile_smoothers and len({bool(st.sog_rate_rts or st.cog_rate_rts) for st in structs}) == 1
+                  and all(st.rts_work and not (st.tuning & 0x200) and ((st.tuning & 0x400) or st.B > lean) and st.Nmax > 0 for st in structs))
+        if merged:
+            okey = ("order",) + skey
+            order = self._schedules.get(okey)
+            if order is None:
+                # tiles in the order the schedule finishes them: last round in which (window, tile) appears
+                tile0 = np.concatenate(([0], np.cumsum(ntiles)))
+                last = np.full(int(tile0[-1]), -1, dtype=np.int64)
+                live = items[..., 0] >= 0
+                rr = np.broadcast_to(np.arange(items.shape[0])[:, None], items.shape[:2])[live]
+                flat = tile0[items[..., 0][live]] + items[..., 1][live]
+                np.maximum.at(last, flat, rr)
+                idx = np.argsort(last, kind="stable")
+                win = np.searchsorted(tile0, idx, side="right") - 1
+                order = np.ascontiguousarray(np.stack([win, idx - tile0[win]], axis=1).astype(np.int32))
+                self._schedules[okey] = order
+            bwd_stream = self._tail_stream if final else self.bwd_streams[k % len(self.bwd_streams)]
+            bwd_stream.wait_event(zeroed)
+            # behind the forward launch's residency: a waiting smoother wave must not sit where a forward wave still has to go
+            binding.check(self.lib.ste_stream_wait_counter(counters_all.data_ptr() + 4 * (n + 1), nwaves, counters.data_ptr() + 4 * n,
+                                                           float(timeout_s) * 4, C.c_void_p(bwd_stream.cuda_stream)),
+                          "ste_stream_wait_counter")
+            sbytes = int(self.lib.ste_urtss_backward_sched_workspace(n, int(order.shape[0])))
+            s_host = s_dev = None
+            for j, (cap, h, d) in enumerate(self._sched_free_bwd):
+                if cap >= sbytes:
+                    s_host, s_dev = h, d
+                    del self._sched_free_bwd[j]
+                    break
+            if s_host is None:
+                cap = max(1 << 18, 1 << (sbytes - 1).bit_length())
+                with torch.cuda.stream(bwd_stream):
+                    s_host = torch.empty(cap, dtype=torch.uint8, pin_memory=self._sched_pinned)
+                    s_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            bs = binding.SteBwdSchedF64()
+            bs.nwindows, bs.windows, bs.slice_steps = n, C.addressof(structs), step
+            bs.nitems, bs.items = int(order.shape[0]), order.ctypes.data
+            bs.host_ws, bs.dev_ws, bs.ws_bytes = s_host.data_ptr(), s_dev.data_ptr(), sbytes
+            bs.progress = dev_ws.data_ptr() + int(self.lib.ste_ukf_forward_sched_progress_offset(n, max(nslices), sum(ntiles), items.shape[0], nwaves))
+            bs.error, bs.timeout_s = counters.data_ptr() + 4 * n, float(timeout_s) * 4
+            if timing is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                timing["smoothers"].append(ev)
+                timing["tile_smoothers"] = True
+                ev[0].record(bwd_stream)
+            binding.check(self.lib.ste_urtss_backward_sched_f64(C.byref(bs), C.c_void_p(bwd_stream.cuda_stream)),
+                          "ste_urtss_backward_sched_f64")
+            if timing is not None:
+                ev[1].record(bwd_stream)
+            done = torch.cuda.Event()
+            done.record(bwd_stream)
+            self._sched_live[-1] = self._sched_live[-1] + ((s_host, s_dev, order),)
+            for db in dbs:
+                if getattr(db, "_pipeline_done", None) is None:
+                    self._batches.append(weakref.ref(db))
+                db._pipeline_done = done
+                events.append(done)
+            return events
         waited = set()
         for i, db in enumerate(dbs):
             if getattr(db, "_pipeline_done", None) is None:
@@ -1056,6 +1131,7 @@ class SmootherPipeline:
         live, self._sched_live = self._sched_live, []
         bad = [int(e[2][-1].item()) for e in live]
         self._sched_free = ([(e[0].numel(), e[0], e[1], e[7]) for e in live] + self._sched_free)[:16]
+        self._sched_free_bwd = ([(e[9][0].numel(), e[9][0], e[9][1]) for e in live if len(e) > 9] + self._sched_free_bwd)[:16]
         if any(bad):
             raise binding.SteError("a scheduled forward launch could not progress (error word %s: 1 = a forward wave, 2 = a smoother "
                                    "gate waited longer than its bound); results of that sequence are incomplete" % bad)
@@ -1086,6 +1162,7 @@ class SmootherPipeline:
             self._batches = []
             self._sched_live = []
             self._sched_free = []
+            self._sched_free_bwd = []
             for dkey in [k for k, v in _last_scheduled.items() if v[4] == id(self)]:  # (drained above: nothing to wait for)
                 del _last_scheduled[dkey]
             self.fwd_streams, self.bwd_streams, self._tail_stream = [], [], None

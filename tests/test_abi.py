@@ -27,7 +27,8 @@ def test_struct_layout_matches_header():
 
     hdr = open(os.path.join(ROOT, "include", "ste.h")).read()
     for cname, mirror in (("ste_ukf_batch_f64", binding.SteUkfBatchF64), ("ste_gp_batch_f64", binding.SteGpBatchF64),
-                          ("ste_prep_batch_f64", binding.StePrepBatchF64), ("ste_fwd_sched_f64", binding.SteFwdSchedF64)):
+                          ("ste_prep_batch_f64", binding.StePrepBatchF64), ("ste_fwd_sched_f64", binding.SteFwdSchedF64),
+                          ("ste_bwd_sched_f64", binding.SteBwdSchedF64)):
         body = hdr[hdr.index("typedef struct %s {" % cname): hdr.index("} %s;" % cname)]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = re.findall(r"(?:const\s+)?(?:int32_t|uint32_t|int64_t|double|size_t|void|ste_ukf_batch_f64)\s*\*?\s*(\w+)\s*;", body)
