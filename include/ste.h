@@ -44,7 +44,7 @@ extern "C" {
 #endif
 
 #define STE_VERSION 321 /* 0.3.2: the forward passes of many windows as one scheduled launch (ste_ukf_forward_sched_f64,
-                           ste_stream_wait_counter).  0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in
+                           ste_stream_wait_counter); 321: their smoothers as one launch too (ste_urtss_backward_sched_f64).  0.3.1: track_stride (windows of a resident fleet), sm_pos, forward pass in
                            time slices (step_begin / step_end).  0.3.0: rts_work rows of 30 doubles (+ B at the end); sigma
                            weights sum to one */
 

@@ -15,6 +15,8 @@
 //                                        and the upload of the schedule's table from page-locked memory
 //   urtss_recur_l1                       smoother from those rows, one lane per track: gain K = D pinv(P_b), recurrence
 //                                        (batches that fill the chip)
+//   urtss_recur_sched                    the same body for every window of a scheduled forward launch as one launch: a wave
+//                                        per tile, waiting for its own tile's forward pass
 //   urtss_gains_all + urtss_recur_lean   the same smoother in two kernels for batches of <= 4 096 tracks: every gain of
 //     / urtss_recur_lean_q4              every (step, track) at once, written back into the work rows, then the bare
 //                                        recurrence, one lane or one DPP quad per track -- bit-identical to urtss_recur_l1
