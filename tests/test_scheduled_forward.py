@@ -117,6 +117,47 @@ def test_schedule_validation_refuses_tables_that_could_not_progress():
     assert lib.ste_ukf_forward_sched_workspace(2, 2, 4, 2, 4) >= 4 * 64 + 8 * 16 + 16
 
 
+def test_scheduled_smoother_validation():
+    """include/ste.h (STE_VERSION 321): ste_urtss_backward_sched_f64 checks windows and tile list before it launches anything
+    (no GPU needed): every window must take the one-kernel smoother, every tile appears once."""
+    lib, keep = binding.load(), []
+    wins = _minimal_windows(2, B=4224, keep=keep)  # 2 windows x 66 tiles, above the two-kernel smoother's bound
+    for w in wins:
+        w.rts_work = w.sm_mean = w.sm_cov = 0x1000
+    ws = np.zeros(1 << 16, dtype=np.uint8)
+    tiles = np.array([(w, t) for w in range(2) for t in range(66)], dtype=np.int32)
+
+    def call(items, **kw):
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        sc = binding.SteBwdSchedF64()
+        sc.nwindows, sc.windows, sc.slice_steps = 2, C.addressof(wins), kw.get("slice_steps", 64)
+        sc.nitems, sc.items = items.shape[0], items.ctypes.data
+        sc.host_ws, sc.dev_ws, sc.ws_bytes = ws.ctypes.data, 0x1000, kw.get("ws_bytes", ws.nbytes)
+        sc.progress, sc.error = 0x1000, 0x1000
+        rc = lib.ste_urtss_backward_sched_f64(C.byref(sc), None)
+        return rc, lib.ste_last_error().decode()
+
+    assert lib.ste_urtss_backward_sched_workspace(2, 132) <= ws.nbytes
+    assert "every tile of every window once" in call(tiles[:-1])[1]
+    bad = tiles.copy()
+    bad[5] = bad[4]
+    assert "appears twice" in call(bad)[1]
+    bad = tiles.copy()
+    bad[5] = (1, 66)
+    assert "does not exist" in call(bad)[1]
+    assert "workspace too small" in call(tiles, ws_bytes=64)[1]
+    assert "multiple of STE_SLICE_ALIGN" in call(tiles, slice_steps=96)[1]
+    wins[1].sog_rate_rts = 0x1000  # one window smooths with rates of its own, the other does not: two kernels
+    assert "must agree on smoother rates" in call(tiles)[1]
+    wins[1].sog_rate_rts = 0
+    wins[1].B = 4096  # the two-kernel smoother's territory: other bits
+    small = np.array([(0, t) for t in range(66)] + [(1, t) for t in range(64)], dtype=np.int32)
+    assert "one-kernel smoother" in call(small)[1]
+    # where the forward launch keeps its per-tile counters: behind its parameter blocks and its item table
+    off = lib.ste_ukf_forward_sched_progress_offset(2, 2, 132, 3, 128)
+    assert 0 < off < lib.ste_ukf_forward_sched_workspace(2, 2, 132, 3, 128) and off % 16 == 0
+
+
 def _uniform(B, seed0, nobs=33, substeps=4):
     H, Q, R, P0 = synthetic.example_matrices()
     sb = synthetic.make_batch(B, nobs=nobs, gap_h=1.0, seed0=seed0)
