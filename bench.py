@@ -632,6 +632,7 @@ def _main(stack):
         # (decided by the SLOWEST of three runs of either form: at the edge of the device's queue slots a form is fast in
         #  one run and twice as slow in the next, and the timed region is one run)
         keep, seq = seq, 0
+        wall(args.steps)  # (this form's first launches on these streams)
         step_all = sorted(wall(args.steps) for _ in range(3))
         step_ms = step_all[-1]
         pipe.close()
