@@ -393,9 +393,9 @@ def _main(stack):
                     help="steps per SCHEDULED forward launch (SmootherPipeline.submit_sequence: the forward passes of that many "
                          "steps as one launch of resident waves over (tile, time slice) items): an integer, 0 = one launch per "
                          "step, or 'auto'.  auto, one GPU and --steps <= 40 (a short run is all fill and drain, which a schedule "
-                         "shortens): two scheduled launches -- the first of as many steps as fill the chip once -- and one launch "
-                         "per step are both run untimed, each on the pipeline it needs (2 + 6 + 1 against 7 + 6 + 1 streams; three runs, "
-                         "the slowest counts), and the faster form is used (config.sequence_auto says which: 0.74-0.77 "
+                         "shortens): two scheduled launches -- the first of as many steps as fill the chip once --, one scheduled "
+                         "launch with one tile-smoother launch, and one launch per step are all run untimed, each on the pipeline it "
+                         "needs (2 + 6 + 1, 1 + 1 + 1 and 7 + 6 + 1 streams; three runs, the slowest counts), and the fastest form is used (config.sequence_auto says which: 0.74-0.77 "
                          "against 0.80 ms per step at the driver's 20 steps); longer runs and runs with an exchange: one launch "
                          "per step (in the steady state per-step launches re-balance by themselves and are 1-2 %% faster; "
                          "DESIGN.md section 5)")
@@ -501,11 +501,13 @@ def _main(stack):
     # 16.5+, one launch per step 16.1 (profiles/r05_scheduled_forward.txt)
     first_fill = max(1, -(-1024 // max(1, -(-B // 64))))
 
+    plan_single = False  # auto's second scheduled form: ONE launch for the run, its smoothers as one launch of waves per tile
+
     def seq_plan(n):
         if not seq or n <= 0:
             return []
         if args.sequence == "auto":
-            return [n] if n <= first_fill + 1 else [first_fill, n - first_fill]
+            return [n] if (n <= first_fill + 1 or plan_single) else [first_fill, n - first_fill]
         return [min(seq, n - c0) for c0 in range(0, n, seq)]
 
     # per-step launches rotate through buffers_needed sets; a scheduled launch needs a set per step of the sequence, and two
@@ -646,18 +648,43 @@ def _main(stack):
             print(f"[bench] scheduled forward launches disabled after an error in the untimed comparison: {exc}", file=sys.stderr, flush=True)
             torch.cuda.synchronize(dev)
             sched_all, sched_ms = None, float("inf")
-        if not sched_ms <= step_ms:
-            seq = 0
+        # third form: the whole run as ONE scheduled launch with its smoothers as one launch of waves per tile -- within 1 % of
+        # the split form on a normal box, and it runs on ONE forward and ONE smoother stream: three hardware queues
+        single_all, single_ms = None, float("inf")
+        if len(seq_plan(args.steps)) > 1:
+            pipe.close()
+            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **dict(kw, forward_streams=1, smoother_streams=1)))
+            plan_single = True
+            try:
+                wall(args.steps)
+                single_all = sorted(wall(args.steps) for _ in range(3))
+                single_ms = single_all[-1]
+            except binding.SteError as exc:
+                print(f"[bench] single scheduled launch disabled after an error in the untimed comparison: {exc}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize(dev)
+                single_all, single_ms = None, float("inf")
+        best = min(step_ms, sched_ms, single_ms)
+        if best == sched_ms and np.isfinite(sched_ms):
+            if plan_single:  # back to the split form's pipeline
+                plan_single = False
+                pipe.close()
+                pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **dict(kw, sequence_only=True)))
+                wall(args.steps)
+        elif best == step_ms:
+            seq, plan_single = 0, False
             pipe.close()
             pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **kw))
             wall(prepass)
         auto_choice = {"scheduled_launches_ms": sched_ms if np.isfinite(sched_ms) else None, "per_step_launches_ms": step_ms,
-                       "scheduled_launches_ms_all": sched_all, "per_step_launches_ms_all": step_all,
-                       "steps": args.steps, "chosen": "scheduled" if seq else "per_step",
+                       "single_launch_ms": single_ms if np.isfinite(single_ms) else None,
+                       "scheduled_launches_ms_all": sched_all, "per_step_launches_ms_all": step_all, "single_launch_ms_all": single_all,
+                       "steps": args.steps, "chosen": ("single_launch" if plan_single else "scheduled") if seq else "per_step",
                        "streams": f"{len(pipe.fwd_streams)} forward + {len(pipe.bwd_streams)} smoother + 1",
-                       "note": "untimed, before the warm-up: wall time of --steps steps in either launch form, each on the "
-                               "pipeline it needs (three runs each, the slowest counts); the timed region uses the faster "
-                               "form -- both give the same histories bit for bit"}
+                       "note": "untimed, before the warm-up: wall time of --steps steps in each launch form -- one launch per "
+                               "step (7 + 6 + 1 streams), scheduled launches of first-fill + rest with a smoother per step "
+                               "(2 + 6 + 1), one scheduled launch with one tile-smoother launch (1 + 1 + 1) --, each on the "
+                               "pipeline it needs, three runs each, the slowest counts; the timed region uses the fastest "
+                               "form -- all give the same histories bit for bit"}
     run_steps(args.warmup)
     drain()
     if dist is not None:
@@ -809,8 +836,10 @@ def _main(stack):
                 "pipeline": ("none: forward and smoother of a step back to back on one stream" if pipe is None else
                              (f"the forward passes of {' + '.join(str(n) for n in seq_plan(args.steps))} steps as ONE scheduled launch each of {4 * (pipe.forward_cus - pipe.reserve_cus)} resident "
                               "waves over (64-track tile, 64-step slice) items (SmootherPipeline.submit_sequence; bit-identical to "
-                              f"per-step launches), each step's smoother behind a gate on one of {len(pipe.bwd_streams)} smoother streams, "
-                              f"{len(dbs)} sets of histories in rotation") if seq else
+                              "per-step launches), " + ("the smoothers of all steps as ONE launch of a wave per 64-track tile that waits for "
+                                                        "its own tile's forward pass (ste_urtss_backward_sched_f64), " if plan_single else
+                                                        f"each step's smoother behind a gate on one of {len(pipe.bwd_streams)} smoother streams, ")
+                              + f"{len(dbs)} sets of histories in rotation") if seq else
                              f"{len(pipe.fwd_streams)} forward passes ({'lane' if pipe.forward_lanes == 1 and not args.lanes else 'quad' if (pipe.forward_lanes == 4 or args.lanes == 4) else 'lane' if args.lanes == 1 else 'auto'}-per-track) in flight "
                              + (f"beside {len(pipe.bwd_streams)} smoothers, all sharing {pipe.forward_cus - pipe.reserve_cus} of the {pipe.forward_cus} CUs "
                                 + (f"({pipe.reserve_cus} left to the collective's kernels) " if pipe.reserve_cus else "") +
@@ -829,7 +858,9 @@ def _main(stack):
                            "scheduled_launches": ([{"steps": n, "forward_ms": tm["forward"][0].elapsed_time(tm["forward"][1]),
                                                     "host_submit_ms": tm["host_ms"]} for n, tm in seq_timings] or None),
                            "note": ("HIP events around every scheduled forward launch (the forward passes of "
-                                    f"{steps_per_launch:g} steps each) and around the smoother of every {EVENT_EVERY}th step" if seq else
+                                    f"{steps_per_launch:g} steps each) and around "
+                                    + ("the ONE smoother launch of the sequence (its duration includes its waves' waits for their tiles)"
+                                       if any(tm.get("tile_smoothers") for _n, tm in seq_timings) else f"the smoother of every {EVENT_EVERY}th step") if seq else
                                     f"HIP events around the forward and smoother kernels of every {EVENT_EVERY}th step of the timed region")},
             "steady_state": steady,
             "all_gather_alone": gather_alone,
