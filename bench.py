@@ -399,6 +399,9 @@ def _main(stack):
                          "against 0.80 ms per step at the driver's 20 steps); longer runs and runs with an exchange: one launch "
                          "per step (in the steady state per-step launches re-balance by themselves and are 1-2 %% faster; "
                          "DESIGN.md section 5)")
+    ap.add_argument("--sequence-form", default="auto", choices=("auto", "per_step", "split", "single"),
+                    help="with --sequence auto: run the untimed comparison of the three launch forms (auto), or pin one of them "
+                         "without comparing (profiling passes)")
     ap.add_argument("--no-fleet", action="store_true", help="skip the `extra.fleet_100k` entry (100 000 distinct tracks through batch.run_fleet)")
     ap.add_argument("--fleet-tracks", type=int, default=100_000)
     ap.add_argument("--fleet-chunk", type=int, default=None, help="window size of the fleet entry (default: batch.FLEET_CHUNK)")
@@ -621,14 +624,29 @@ def _main(stack):
     # on three boxes of round 5 something else on the device held the rest for a while, and scheduled launches took twice
     # their time while per-step launches kept theirs: DESIGN.md section 5)
     auto_choice = None
-    if seq and args.sequence == "auto":
-        def wall(n):
-            torch.cuda.synchronize(dev)
-            tw = time.perf_counter()
-            run_steps(n)
-            drain()
-            return (time.perf_counter() - tw) * 1e3
 
+    def wall(n):
+        torch.cuda.synchronize(dev)
+        tw = time.perf_counter()
+        run_steps(n)
+        drain()
+        return (time.perf_counter() - tw) * 1e3
+
+    if seq and args.sequence == "auto" and args.sequence_form != "auto":
+        # the comparison pinned to one form (profiling passes: rocprofv3 sits on queue creation, and the comparison's three
+        # pipelines, built and destroyed one after the other, are erratic under it -- profiles/README.md)
+        if args.sequence_form == "per_step":
+            seq = 0
+        else:
+            plan_single = args.sequence_form == "single" and len(seq_plan(args.steps)) > 1
+            pipe.close()
+            pipe = stack.enter_context(batch.SmootherPipeline(dev, ntracks=bmax, **(dict(kw, forward_streams=1, smoother_streams=1) if plan_single
+                                                                                     else dict(kw, sequence_only=True))))
+        wall(prepass)
+        auto_choice = {"chosen": ("single_launch" if plan_single else "scheduled") if seq else "per_step", "steps": args.steps,
+                       "streams": f"{len(pipe.fwd_streams)} forward + {len(pipe.bwd_streams)} smoother + 1",
+                       "note": f"--sequence-form {args.sequence_form}: no comparison was run"}
+    elif seq and args.sequence == "auto":
         # Each form on the pipeline it needs, one pipeline alive at a time: per-step launches on the 7 + 6 + 1 streams built
         # above; scheduled launches on 2 + 6 + 1 (sequence_only) -- five hardware queues fewer to hold while they run.
         # (decided by the SLOWEST of three runs of either form: at the edge of the device's queue slots a form is fast in
