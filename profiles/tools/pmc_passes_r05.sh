@@ -20,8 +20,7 @@ python3 bench.py --steps 100 --warmup 10 --no-gp > $O/bench_k100.json 2> $O/benc
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err
 # the driver's form runs its forward passes as scheduled launches (7 + 13 steps) (bench.py --sequence auto): its own kernel stats
 cd /tmp
-# (--sequence-form single: the form the untimed comparison of --sequence auto takes on a normal box, pinned -- under rocprofv3, which
-#  sits on queue creation, the comparison's three pipelines built and destroyed one after the other run erratically)
+# (--sequence-form single: the form the untimed comparison of --sequence auto usually ends on, pinned so that the stats show one form)
 rm -rf $O/stats_driver_form
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_driver_form -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-tracks 0 --no-gp --no-fleet --sequence-form single > $O/stats_driver_form.log 2>&1; echo "stats_driver_form exit $?" >> $O/exits.txt
 cd $R

@@ -1144,6 +1144,34 @@ class SmootherPipeline:
         if self._sched_live:
             self._check_scheduled()
 
+    def shrink(self, forward_streams: int, smoother_streams: int):
+        """Drain the pipeline and destroy all but its first ``forward_streams`` forward and ``smoother_streams`` smoother
+        streams: the hardware queues of a pipeline that goes on with scheduled launches only (they need two forward streams,
+        one when sequences do not overlap; tile smoothers need one smoother stream) go back to the device without a new
+        pipeline -- new queues -- being built."""
+        if forward_streams < 1 or smoother_streams < 1:
+            raise ValueError("forward_streams and smoother_streams must be >= 1")
+        self.synchronize()
+        for ref in self._batches:  # (events recorded on streams that are about to go)
+            db = ref()
+            if db is not None and getattr(db, "_pipeline_done", None) is not None:
+                db._pipeline_done = None
+        self._batches = []
+        for dkey in [k for k, v in _last_scheduled.items() if v[4] == id(self)]:
+            del _last_scheduled[dkey]
+        drop = self.fwd_streams[forward_streams:] + self.bwd_streams[smoother_streams:]
+        self.fwd_streams, self.bwd_streams = self.fwd_streams[:forward_streams], self.bwd_streams[:smoother_streams]
+        gone = {int(st.cuda_stream) for st in drop}
+        del drop
+        keep = []
+        for h in self._raw:
+            if h is not None and h.value and int(h.value) in gone:
+                self.lib.ste_stream_destroy(h)
+            else:
+                keep.append(h)
+        self._raw = keep
+        self.buffers_needed = len(self.fwd_streams) + len(self.bwd_streams) + 1
+
     @property
     def closed(self) -> bool:
         return not self._raw and not self.fwd_streams and not self.bwd_streams
