@@ -350,3 +350,42 @@ def test_scheduled_launches_of_two_pipelines_become_resident_one_at_a_time():
             for r, group in zip(refs, seqs):
                 for d in group:
                     assert _same(r, d), rep
+
+
+@pytest.mark.gpu
+def test_pipeline_shrinks_to_the_streams_scheduled_launches_need():
+    """SmootherPipeline.shrink hands hardware queues back without building new ones (bench.py --sequence auto goes from the
+    7 + 6 + 1 streams of per-step launches to 2 + 6 + 1 and 1 + 1 + 1 that way): same results on what is left."""
+    import torch
+
+    _, hb = _uniform(5000, 6_600_000, nobs=33, substeps=4)  # above the two-kernel smoother's bound: tile smoothers apply
+    hb.lanes = 1
+    ref = _clear(batch.DeviceBatch(hb))
+    ref.run()
+    torch.cuda.synchronize()
+    seqs = [_clear(batch.DeviceBatch(hb)) for _ in range(4)]
+    with batch.SmootherPipeline(ntracks=5000) as pipe:
+        nf, nb = len(pipe.fwd_streams), len(pipe.bwd_streams)
+        assert nf > 2 and nb > 1
+        for i, d in enumerate(seqs):
+            pipe.submit(d, final=(i == len(seqs) - 1))
+        pipe.synchronize()
+        assert all(_same(ref, d) for d in seqs)
+        pipe.shrink(2, nb)
+        assert (len(pipe.fwd_streams), len(pipe.bwd_streams), pipe.buffers_needed) == (2, nb, nb + 3) and len(pipe._raw) == nb + 2
+        for d in seqs:
+            _clear(d)
+        pipe.submit_sequence(seqs[:2], final=False)
+        pipe.submit_sequence(seqs[2:])
+        pipe.synchronize()
+        assert all(_same(ref, d) for d in seqs)
+        pipe.shrink(1, 1)
+        assert (len(pipe.fwd_streams), len(pipe.bwd_streams), pipe.buffers_needed) == (1, 1, 3) and len(pipe._raw) == 2
+        for d in seqs:
+            _clear(d)
+        pipe.submit_sequence(seqs)
+        assert len(pipe._sched_live[-1]) > 9  # one smoother launch, a wave per tile
+        pipe.synchronize()
+        assert all(_same(ref, d) for d in seqs)
+        with pytest.raises(ValueError):
+            pipe.shrink(0, 1)
