@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    for k in ("ukf_forward_sched", "sched_gate", "ukf_forward_l1", "ukf_forward_q4", "urtss_smooth_wg", "urtss_recur_l1", "urtss_backward_l1"):
+    for k in ("ukf_forward_sched", "urtss_recur_sched", "sched_gate", "sched_upload", "ukf_forward_l1", "ukf_forward_q4", "urtss_smooth_wg", "urtss_recur_l1", "urtss_backward_l1"):
         if k in name:
             return k
     return None
