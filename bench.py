@@ -29,7 +29,11 @@ Prints ONE JSON line on rank 0.  Extra objects:
 Steps are pipelined by default (track_estimators.batch.SmootherPipeline): every step runs the complete forward pass
 and smoother of one batch, but several steps are in flight -- forward passes and the smoothers of the steps before them
 share every compute unit (one forward wave per SIMD by construction, smoother waves beside them), each stream on a
-hardware queue of its own, with one set of history buffers per step in flight plus one.
+hardware queue of its own, with one set of history buffers per step in flight plus one.  A short run on one GPU
+(``--steps`` <= 40, ``--sequence auto``) is mostly fill and drain, and three launch forms of the same arithmetic (same bits)
+are compared untimed first: one launch pair per step; the forward passes of the run as two scheduled launches of resident
+waves over (tile, time slice) items with a smoother per step; ONE scheduled forward launch with ONE smoother launch of a
+wave per tile -- the line says which form it timed and what each cost (``config.sequence_auto``).
 """
 import argparse
 import contextlib
